@@ -1,0 +1,234 @@
+/*
+ * amenv.h -- C ABI of libamenv.so: the MI355X-resident batched waypoint environment.
+ *
+ * This is the drop-in boundary for ONE path of LahiruCooray/rl-aerial-manipulator:
+ * `WaypointQuadEnv.step()/reset()` and the `simul_files` rigid-body integrator, stepped
+ * for N independent environments per call instead of one.  The reference has no FFI
+ * (it is pure Python); every entry point below names the reference interface it
+ * replaces as  <file>:<line>  relative to the reference root, with
+ *   v2 = initial-implementation-v2,  v1 = initial-implementation-v1.
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, fixed-width ints.  No torch / HIP types in signatures:
+ *    a stream is passed as `void*` (a hipStream_t; NULL = the default stream).
+ *  - all I/O buffers are DEVICE pointers owned by the caller (e.g. torch tensors);
+ *    the library owns only its internal struct-of-arrays episode state.
+ *  - every call only ENQUEUES work on the given stream: no hidden synchronisation, no
+ *    allocation after amenv_create(), safe to capture into a hipGraph.
+ *  - return value: 0 = AMENV_OK, negative = error code; text via amenv_last_error().
+ *    Nothing throws, nothing calls exit().
+ *  - one handle per device; calls on one handle are serialised by the caller.
+ *    There is no global state: 8 handles on 8 GPUs can be driven from 8 processes/threads.
+ */
+#ifndef AMENV_H_
+#define AMENV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMENV_ABI_VERSION 1
+
+#define AMENV_MAX_ROTORS 8
+#define AMENV_MAX_WAYPOINTS 4
+#define AMENV_MAX_JOINTS 3
+
+/* error codes */
+#define AMENV_OK 0
+#define AMENV_ERR_INVALID -1   /* bad argument / config                       */
+#define AMENV_ERR_HIP -2       /* a HIP runtime call failed (see last_error)   */
+#define AMENV_ERR_NO_DEVICE -3 /* no usable gfx950 device                      */
+#define AMENV_ERR_ALLOC -4
+
+/* arithmetic type of the dynamics + episode state */
+#define AMENV_F32 0 /* product path: fp32 SoA state, fp32 reward                         */
+#define AMENV_F64 1 /* logic-check build of the SAME kernel in fp64 (reward/state fp64)  */
+
+/* amenv_config.flags */
+#define AMENV_FLAG_AUTO_RESET 1u /* SB3 VecEnv semantics: done envs are reset inside step()      */
+#define AMENV_FLAG_NAN_GUARD 2u  /* non-finite state => terminated|NONFINITE (documented deviation) */
+
+/* task variants (which reference env file the step semantics follow) */
+#define AMENV_TASK_V2_SCALED20 0 /* v2/rl_env_scaledObs.py  (20-D scaled obs) */
+#define AMENV_TASK_V1_SCALED17 1 /* v1/rl_env_scaledObs.py  (17-D scaled obs) */
+#define AMENV_TASK_V1_RAW17 2    /* v1/rl_env.py            (17-D raw obs)    */
+
+/* info_bits[i], one uint32 per env per step (the reference's `info` dict + flags,
+ * v2/rl_env_scaledObs.py:164,173,179,192,195,196) */
+#define AMENV_INFO_TERMINATED 1u
+#define AMENV_INFO_TRUNCATED 2u
+#define AMENV_INFO_SUCCESS 4u
+#define AMENV_INFO_STOPPED 8u
+#define AMENV_INFO_CRASHED 16u
+#define AMENV_INFO_OOB 32u
+#define AMENV_INFO_NONFINITE 64u /* only with AMENV_FLAG_NAN_GUARD */
+#define AMENV_INFO_WAS_RESET 128u /* this env was auto-reset at the end of this step */
+
+/* Vehicle: n-rotor rigid body.  Replaces v2/simul_files/model/params.py:10-36.
+ * All matrices row-major.  Rotor thrusts T = alloc . [F,Mx,My,Mz]^T, each clamped to
+ * [t_min,t_max], then [F',Mx',My',Mz']^T = mix . T   (v2/simul_files/model/quadcopter.py:109-112). */
+typedef struct amenv_vehicle {
+  int32_t n_rotors; /* 1..AMENV_MAX_ROTORS */
+  int32_t n_joints; /* 0 = rigid body; 3 = hexacopter + 3-link arm */
+  double mass;      /* kg  (params.py:10) */
+  double g;         /* m/s^2 (params.py:11) */
+  double inertia[9];     /* body inertia I (params.py:12-14) */
+  double inv_inertia[9]; /* I^-1 (params.py:16) */
+  double alloc[AMENV_MAX_ROTORS * 4]; /* [n_rotors][4]  (params.py:36 invA) */
+  double mix[4 * AMENV_MAX_ROTORS];   /* [4][n_rotors]  (params.py:31-34 A) */
+  double t_min[AMENV_MAX_ROTORS];     /* per-rotor thrust floor (params.py:19, minF/4) */
+  double t_max[AMENV_MAX_ROTORS];     /* per-rotor thrust cap   (params.py:20, maxF/4) */
+  double moment_scale;   /* M = a[1:4]*moment_scale, evaluated in fp32 (rl_env_scaledObs.py:126: 0.1) */
+  /* arm (n_joints = 3) parameters; ignored for n_joints = 0.  See DESIGN.md "arm". */
+  double joint_origin[AMENV_MAX_JOINTS * 3]; /* joint frame origin in parent link frame */
+  double joint_axis[AMENV_MAX_JOINTS * 3];   /* unit axis in the child frame */
+  double link_mass[AMENV_MAX_JOINTS];
+  double link_com[AMENV_MAX_JOINTS * 3];     /* link CoM in its own frame */
+  double link_inertia[AMENV_MAX_JOINTS * 9]; /* about the link CoM, link frame */
+  double joint_kp, joint_kd, joint_tau_max, joint_damping;
+  double joint_limit[AMENV_MAX_JOINTS * 2];
+} amenv_vehicle;
+
+/* Task constants that the reference keeps as literals in rl_env_scaledObs.py. */
+typedef struct amenv_task {
+  int32_t variant;           /* AMENV_TASK_* */
+  int32_t num_waypoints;     /* K; reference hard-codes 1 (rl_env_scaledObs.py:47) */
+  int32_t max_episode_steps; /* 2000 (rl_env_scaledObs.py:56) */
+  int32_t counter_limit;     /* 500  (rl_env_scaledObs.py:59) */
+  int32_t rk4_substeps;      /* RK4 sub-steps per control step; 1 */
+  int32_t reserved0;
+  double dt;                 /* 1/200 (rl_env_scaledObs.py:30) */
+  /* sin(2*pi*k/K), cos(2*pi*k/K), k = 1..K: used by the curved / helical waypoint
+   * generators (v2/utils2/utils.py:39,46,53,83-87); filled by amenv_default_config(). */
+  double traj_sin[AMENV_MAX_WAYPOINTS];
+  double traj_cos[AMENV_MAX_WAYPOINTS];
+} amenv_task;
+
+typedef struct amenv_config {
+  uint32_t struct_size; /* = sizeof(amenv_config): ABI guard */
+  uint32_t abi_version; /* = AMENV_ABI_VERSION */
+  int32_t num_envs;     /* N on THIS device */
+  int32_t dtype;        /* AMENV_F32 | AMENV_F64 */
+  uint32_t flags;       /* AMENV_FLAG_* */
+  int32_t block_size;   /* 0 = auto; else threads per workgroup (multiple of 64) */
+  uint64_t seed;        /* reset RNG seed (Philox4x32-10 key) */
+  int64_t env_id_offset; /* global id of local env 0: RNG is keyed by GLOBAL env id, so
+                            results do not depend on how envs are sharded over GPUs */
+  amenv_vehicle vehicle;
+  amenv_task task;
+} amenv_config;
+
+/* Episode state, struct-of-arrays.  Float fields are `dtype` (fp32 or fp64), laid out
+ * field-major: fstate[field][env], istate[field][env].  Replaces the attribute set of
+ * WaypointQuadEnv (rl_env_scaledObs.py:26-38,53-77) + Quadcopter.state (quadcopter.py:28). */
+enum amenv_float_field {
+  AMENV_F_PX = 0, AMENV_F_PY, AMENV_F_PZ,          /* position            state[0:3]  */
+  AMENV_F_VX, AMENV_F_VY, AMENV_F_VZ,              /* velocity            state[3:6]  */
+  AMENV_F_QW, AMENV_F_QX, AMENV_F_QY, AMENV_F_QZ,  /* attitude quaternion state[6:10] */
+  AMENV_F_WX, AMENV_F_WY, AMENV_F_WZ,              /* body rates p,q,r    state[10:13]*/
+  AMENV_F_FINAL_YAW,                               /* rl_env_scaledObs.py:72          */
+  AMENV_F_LAST_DISTANCE,                           /* :76 ; < 0 encodes None          */
+  AMENV_F_EP_RETURN,                               /* Monitor-style running return    */
+  AMENV_F_WP0                                      /* waypoints: WP0 + 3*k + {0,1,2}  */
+  /* with n_joints = 3: joint angle, rate, target follow the waypoints (see amenv_state_dims) */
+};
+enum amenv_int_field {
+  AMENV_I_STEP = 0,   /* current_step (:55)                                         */
+  AMENV_I_COUNTER,    /* counter (:57)                                              */
+  AMENV_I_FLAGS,      /* bits 0-7 waypoint_index, bit 8 final_waypoint_reached, bit 9 counter_activated */
+  AMENV_I_EPISODE,    /* episodes started so far by this env (RNG counter)          */
+  AMENV_I_NFIELDS
+};
+#define AMENV_FLAGBIT_FWR 256
+#define AMENV_FLAGBIT_COUNTER_ACTIVE 512
+
+/* Running totals since amenv_create / amenv_stats(reset=1): the Monitor / rollout
+ * aggregates, reduced on the GPU (wavefront reduction + one atomic per wave). */
+typedef struct amenv_stats {
+  uint64_t steps;       /* env-steps executed */
+  uint64_t episodes;    /* episodes finished  */
+  uint64_t terminated, truncated, success, crashed, oob, nonfinite;
+  uint64_t length_sum;  /* sum of finished episode lengths */
+  int64_t return_sum_q10; /* sum of finished episode returns, fixed point 2^-10 (order-independent) */
+} amenv_stats;
+
+typedef struct amenv amenv; /* opaque */
+
+/* ---- configuration helpers (host only, no device needed) ------------------------- */
+
+/* Fill *cfg with the reference's own constants: the 0.18 kg quadrotor of
+ * v2/simul_files/model/params.py and the v2 task literals.  vehicle_name:
+ * "quad" (reference, oracle-pinned) | "hexa" | "hexa_arm" (hexacopter_description/
+ * and Manipulator/ SDF parameters; no reference dynamics => parity unpinned). */
+int amenv_default_config(const char* vehicle_name, int32_t num_envs, amenv_config* cfg);
+
+/* obs_dim / act_dim / number of float state fields for a config. */
+int amenv_dims(const amenv_config* cfg, int32_t* obs_dim, int32_t* act_dim, int32_t* n_float_fields,
+               int32_t* n_int_fields);
+
+/* Algorithmic HBM bytes of one env-step of amenv_step() for this config (DESIGN.md formula). */
+int64_t amenv_bytes_per_env_step(const amenv_config* cfg);
+
+const char* amenv_version(void);
+
+/* ---- lifetime --------------------------------------------------------------------- */
+
+/* Replaces WaypointQuadEnv.__init__ (rl_env_scaledObs.py:10-38) x N and
+ * make_vec_env(WaypointQuadEnv, n_envs=N) (v2/rl_train.py:24). */
+int amenv_create(const amenv_config* cfg, int device, amenv** out);
+int amenv_destroy(amenv* env);
+/* Text of the last error on this handle (env may be NULL: last create error). */
+const char* amenv_last_error(const amenv* env);
+
+/* ---- the hot path ----------------------------------------------------------------- */
+
+/* Replaces WaypointQuadEnv.reset (rl_env_scaledObs.py:40-79) for every env whose mask
+ * byte is non-zero (mask NULL = all).  obs_out [N,obs_dim] f32 row-major may be NULL;
+ * rows of un-reset envs are rewritten with their current observation. */
+int amenv_reset(amenv* env, const uint8_t* mask, float* obs_out, void* stream);
+
+/* Replaces, for all N envs in ONE kernel launch:
+ *   WaypointQuadEnv.step          rl_env_scaledObs.py:123-196
+ *   Quadcopter.update/state_dot   simul_files/model/quadcopter.py:66-114  (RK4 for odeint)
+ *   _calculate_reward             rl_env_scaledObs.py:198-231
+ *   _get_observation              rl_env_scaledObs.py:98-121
+ *   quaternion_to_rpy             utils2/utils.py:4-9
+ *   DummyVecEnv.step_wait auto-reset + Monitor episode stats (SB3; v2/rl_train.py:24)
+ * actions      [N,act_dim] f32 row-major (already clipped by the caller, as SB3 does)
+ * obs          [N,obs_dim] f32   next observation (post-reset for done envs when AUTO_RESET)
+ * reward       [N] f32 (f64 when dtype = AMENV_F64)
+ * done         [N] u8   terminated|truncated
+ * info_bits    [N] u32  AMENV_INFO_*
+ * terminal_obs [N,obs_dim] f32 or NULL: row i written only when done[i]
+ * ep_return    [N] f32 or NULL, ep_len [N] i32 or NULL: written only when done[i] */
+int amenv_step(amenv* env, const float* actions, float* obs, void* reward, uint8_t* done,
+               uint32_t* info_bits, float* terminal_obs, float* ep_return, int32_t* ep_len, void* stream);
+
+/* T consecutive steps in ONE launch with open-loop actions [T,N,act_dim] (action replay /
+ * action repeat).  Per-step outputs are [T,N,...] or NULL; state stays in registers between
+ * steps.  Same per-step semantics as amenv_step (including auto-reset). */
+int amenv_rollout(amenv* env, int32_t n_steps, const float* actions, float* obs, void* reward,
+                  uint8_t* done, uint32_t* info_bits, void* stream);
+
+/* ---- state access (parity injection, checkpoint/restore) --------------------------- */
+
+/* Copy the whole SoA episode state to / from caller DEVICE buffers:
+ * fstate [n_float_fields][N] of dtype, istate [AMENV_I_NFIELDS][N] int32. */
+int amenv_get_state(amenv* env, void* fstate, int32_t* istate, void* stream);
+int amenv_set_state(amenv* env, const void* fstate, const int32_t* istate, void* stream);
+
+/* Recompute observations of the current state (no stepping): _get_observation, :98-121. */
+int amenv_observe(amenv* env, float* obs_out, void* stream);
+
+/* Copy the running totals to *host_out (synchronises the stream); optionally zero them. */
+int amenv_stats_read(amenv* env, amenv_stats* host_out, int reset, void* stream);
+
+/* Name, VGPR count etc. of the step kernel chosen for this handle (for bench/profiles). */
+const char* amenv_kernel_name(const amenv* env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMENV_H_ */

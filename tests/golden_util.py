@@ -1,0 +1,45 @@
+"""Helpers shared by the oracle (CPU) and HIP (GPU) parity tests: golden-vector loading."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EPISODES = ["policy_ep0", "policy_ep1", "policy_ep2", "policy_ep3", "openloop_1000", "crash", "oob", "timelimit",
+            "saturation", "reach_and_leave"]
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def teacher_forced_inputs(d):
+    """Arrays, one row per step t, holding the reference env's state BEFORE step t."""
+    T = d["actions"].shape[0]
+    return dict(
+        T=T,
+        state=d["state"][:T], waypoints=d["waypoints"], final_yaw=float(d["final_yaw"]),
+        last_distance=d["var_last_distance"][:T], waypoint_index=d["var_waypoint_index"][:T], fwr=d["var_fwr"][:T],
+        counter=d["var_counter"][:T], counter_activated=d["var_counter_activated"][:T], current_step=d["var_current_step"][:T],
+        actions=d["actions"],
+    )
+
+
+def fill_blob(fstate, istate, d, K=1):
+    """Write the teacher-forced inputs of episode d into SoA blobs (column t = state before step t)."""
+    from oracle import oracle as O  # field indices only
+
+    tf = teacher_forced_inputs(d)
+    T = tf["T"]
+    fstate[0:13, :T] = tf["state"].T
+    fstate[O.F_FINAL_YAW, :T] = tf["final_yaw"]
+    ld = tf["last_distance"].astype(np.float64)
+    fstate[O.F_LAST_DISTANCE, :T] = np.where(np.isnan(ld), -1.0, ld)
+    fstate[O.F_EP_RETURN, :T] = 0.0
+    wp = np.asarray(tf["waypoints"], np.float64).reshape(-1)
+    fstate[O.F_WP0:O.F_WP0 + wp.size, :T] = wp[:, None]
+    istate[O.I_STEP, :T] = tf["current_step"]
+    istate[O.I_COUNTER, :T] = tf["counter"]
+    istate[O.I_FLAGS, :T] = (tf["waypoint_index"].astype(np.int32) & 255) | np.where(tf["fwr"], O.FLAGBIT_FWR, 0) | np.where(
+        tf["counter_activated"], O.FLAGBIT_COUNTER_ACTIVE, 0)
+    istate[O.I_EPISODE, :T] = 1
+    return tf
