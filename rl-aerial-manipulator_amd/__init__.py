@@ -1,0 +1,13 @@
+"""rl-aerial-manipulator_amd -- MI355X-native batched replacement for the one hot path of
+LahiruCooray/rl-aerial-manipulator: `WaypointQuadEnv.step()/reset()` + the `simul_files`
+rigid-body integrator.  HIP kernels behind a C ABI (include/amenv.h);
+this package is the thin host-side mirror of the reference's Python interface.
+
+The directory name carries a hyphen (project convention), so import it through the alias
+module at the repo root:  `import rl_aerial_manipulator_amd as amd`.
+"""
+from . import _lib
+from ._lib import AmenvError
+from .gpu_env import GpuWaypointEnv
+
+__all__ = ["GpuWaypointEnv", "AmenvError", "_lib"]

@@ -1,0 +1,101 @@
+"""ctypes binding of libamenv.so (include/amenv.h).  There is NO CPU fallback: if the HIP
+library is missing or no gfx950 device is visible, creation fails loudly."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libamenv.so")
+
+MAX_ROTORS, MAX_WAYPOINTS, MAX_JOINTS = 8, 4, 3
+ABI_VERSION = 1
+F32, F64 = 0, 1
+FLAG_AUTO_RESET, FLAG_NAN_GUARD = 1, 2
+INFO_TERMINATED, INFO_TRUNCATED, INFO_SUCCESS, INFO_STOPPED, INFO_CRASHED, INFO_OOB, INFO_NONFINITE, INFO_WAS_RESET = (1 << i for i in range(8))
+F_FINAL_YAW, F_LAST_DISTANCE, F_EP_RETURN, F_WP0 = 13, 14, 15, 16
+I_STEP, I_COUNTER, I_FLAGS, I_EPISODE, I_NFIELDS = 0, 1, 2, 3, 4
+FLAGBIT_FWR, FLAGBIT_COUNTER_ACTIVE = 256, 512
+
+
+class Vehicle(C.Structure):
+    _fields_ = [
+        ("n_rotors", C.c_int32), ("n_joints", C.c_int32), ("mass", C.c_double), ("g", C.c_double),
+        ("inertia", C.c_double * 9), ("inv_inertia", C.c_double * 9),
+        ("alloc", C.c_double * (MAX_ROTORS * 4)), ("mix", C.c_double * (4 * MAX_ROTORS)),
+        ("t_min", C.c_double * MAX_ROTORS), ("t_max", C.c_double * MAX_ROTORS), ("moment_scale", C.c_double),
+        ("joint_origin", C.c_double * (MAX_JOINTS * 3)), ("joint_axis", C.c_double * (MAX_JOINTS * 3)),
+        ("link_mass", C.c_double * MAX_JOINTS), ("link_com", C.c_double * (MAX_JOINTS * 3)),
+        ("link_inertia", C.c_double * (MAX_JOINTS * 9)),
+        ("joint_kp", C.c_double), ("joint_kd", C.c_double), ("joint_tau_max", C.c_double), ("joint_damping", C.c_double),
+        ("joint_limit", C.c_double * (MAX_JOINTS * 2)),
+    ]
+
+
+class Task(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("num_waypoints", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("counter_limit", C.c_int32), ("rk4_substeps", C.c_int32), ("reserved0", C.c_int32), ("dt", C.c_double),
+        ("traj_sin", C.c_double * MAX_WAYPOINTS), ("traj_cos", C.c_double * MAX_WAYPOINTS),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int32), ("dtype", C.c_int32),
+        ("flags", C.c_uint32), ("block_size", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
+        ("vehicle", Vehicle), ("task", Task),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("steps", "episodes", "terminated", "truncated", "success", "crashed", "oob", "nonfinite", "length_sum")] + [
+        ("return_sum_q10", C.c_int64)]
+
+
+class AmenvError(RuntimeError):
+    pass
+
+
+# every symbol include/amenv.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "amenv_version": (C.c_char_p, []),
+    "amenv_default_config": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(Config)]),
+    "amenv_dims": (C.c_int, [C.POINTER(Config)] + [C.POINTER(C.c_int32)] * 4),
+    "amenv_bytes_per_env_step": (C.c_int64, [C.POINTER(Config)]),
+    "amenv_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(_P)]),
+    "amenv_destroy": (C.c_int, [_P]),
+    "amenv_last_error": (C.c_char_p, [_P]),
+    "amenv_reset": (C.c_int, [_P, _P, _P, _P]),
+    "amenv_step": (C.c_int, [_P] * 10),
+    "amenv_rollout": (C.c_int, [_P, C.c_int32] + [_P] * 6),
+    "amenv_get_state": (C.c_int, [_P] * 4),
+    "amenv_set_state": (C.c_int, [_P] * 4),
+    "amenv_observe": (C.c_int, [_P, _P, _P]),
+    "amenv_stats_read": (C.c_int, [_P, C.POINTER(Stats), C.c_int, _P]),
+    "amenv_kernel_name": (C.c_char_p, [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libamenv.so and bind every symbol.  Raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AmenvError(f"{LIB_PATH} not found: build it with __graft_entry__.build() "
+                             f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def default_config(vehicle="quad", num_envs=1):
+    cfg = Config()
+    rc = load().amenv_default_config(vehicle.encode(), num_envs, C.byref(cfg))
+    if rc != 0:
+        raise AmenvError(load().amenv_last_error(None).decode())
+    return cfg

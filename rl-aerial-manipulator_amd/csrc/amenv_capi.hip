@@ -1,0 +1,416 @@
+// amenv_capi.hip -- host side of libamenv.so: the C ABI declared in include/amenv.h.
+// Owns the SoA episode state on one device, validates arguments, picks the kernel
+// instantiation (arithmetic type x rotor count x workgroup size) and enqueues it on the
+// caller's stream.  No synchronisation and no allocation after amenv_create().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "amenv_kernels.hpp"
+
+using namespace amenv_dev;
+
+struct amenv {
+  amenv_config cfg;
+  int device = -1;
+  int obs_dim = kObsDim, act_dim = kActDim, nf = 0;
+  void* fstate = nullptr;
+  int32_t* istate = nullptr;
+  unsigned long long* stats = nullptr;
+  size_t fbytes = 0, ibytes = 0;
+  int block = 64;
+  uint64_t steps = 0;
+  std::string err;
+  std::string kname;
+};
+
+static thread_local std::string g_create_err;
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1, dev;
+  explicit DeviceGuard(int d) : dev(d) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+};
+
+int fail(amenv* e, int code, const std::string& msg) {
+  if (e) e->err = msg; else g_create_err = msg;
+  return code;
+}
+
+#define AMENV_HIP(e, call)                                                                       \
+  do {                                                                                           \
+    hipError_t _s = (call);                                                                      \
+    if (_s != hipSuccess) return fail(e, AMENV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s)); \
+  } while (0)
+
+// small dense helpers (host, fp64) for the default vehicles
+bool invert(int n, const double* a, double* out) {  // Gauss-Jordan, partial pivoting, n <= 4
+  double m[4][8];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) { m[i][j] = a[i * n + j]; m[i][n + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < n; c++) {
+    int p = c;
+    for (int r = c + 1; r < n; r++) if (std::fabs(m[r][c]) > std::fabs(m[p][c])) p = r;
+    if (std::fabs(m[p][c]) < 1e-300) return false;
+    if (p != c) for (int j = 0; j < 2 * n; j++) std::swap(m[c][j], m[p][j]);
+    const double d = m[c][c];
+    for (int j = 0; j < 2 * n; j++) m[c][j] /= d;
+    for (int r = 0; r < n; r++) if (r != c) { const double f = m[r][c]; for (int j = 0; j < 2 * n; j++) m[r][j] -= f * m[c][j]; }
+  }
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) out[i * n + j] = m[i][n + j];
+  return true;
+}
+
+// alloc = A^T (A A^T)^-1  (right pseudo-inverse of the 4 x n mixer; = A^-1 for n = 4)
+bool allocation_from_mix(int n, const double* A /*[4][n]*/, double* alloc /*[n][4]*/) {
+  double G[16], Gi[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) { double s = 0; for (int r = 0; r < n; r++) s += A[i * n + r] * A[j * n + r]; G[i * 4 + j] = s; }
+  if (!invert(4, G, Gi)) return false;
+  for (int r = 0; r < n; r++)
+    for (int j = 0; j < 4; j++) { double s = 0; for (int i = 0; i < 4; i++) s += A[i * n + r] * Gi[i * 4 + j]; alloc[r * 4 + j] = s; }
+  return true;
+}
+
+void fill_task_defaults(amenv_task* t, int K) {
+  t->variant = AMENV_TASK_V2_SCALED20;
+  t->num_waypoints = K;          // rl_env_scaledObs.py:47
+  t->max_episode_steps = 2000;   // :56
+  t->counter_limit = 500;        // :59
+  t->rk4_substeps = 1;
+  t->dt = 1.0 / 200.0;           // :30
+  const double pi = 3.14159265358979323846;
+  for (int k = 1; k <= K; k++) {
+    const double tt = double(k) / double(K);
+    t->traj_sin[k - 1] = std::sin(2.0 * tt * pi);   // utils2/utils.py:39
+    t->traj_cos[k - 1] = std::cos(tt * 2.0 * pi);   // utils2/utils.py:83-86
+  }
+}
+
+// the reference's 0.18 kg quadrotor: v2/simul_files/model/params.py:10-36
+bool vehicle_quad(amenv_vehicle* v) {
+  v->n_rotors = 4; v->n_joints = 0;
+  v->mass = 0.18; v->g = 9.81;
+  const double I[9] = {0.00025, 0, 2.55e-6, 0, 0.000232, 0, 2.55e-6, 0, 0.0003738};
+  std::memcpy(v->inertia, I, sizeof(I));
+  if (!invert(3, I, v->inv_inertia)) return false;
+  const double L = 0.086, r = 1.5e-9 / 6.11e-8;
+  const double A[16] = {1, 1, 1, 1, 0, L, 0, -L, -L, 0, L, 0, r, -r, r, -r};
+  std::memcpy(v->mix, A, sizeof(A));
+  if (!invert(4, A, v->alloc)) return false;
+  const double maxF = 2.0 * v->mass * v->g, minF = 0.0;
+  for (int i = 0; i < 4; i++) { v->t_min[i] = minF / 4; v->t_max[i] = maxF / 4; }
+  v->moment_scale = 0.1;  // rl_env_scaledObs.py:126
+  return true;
+}
+
+// The repo's 6-rotor airframe (hexacopter_description/custom_hexa/model.sdf + airframe/4022_*):
+// no reference dynamics code exists for it -> parity unpinned; constants derived in DESIGN.md "hexa".
+bool vehicle_hexa(amenv_vehicle* v) {
+  v->n_rotors = 6; v->n_joints = 0;
+  v->mass = 2.7211; v->g = 9.81;
+  // composite inertia about the CoG: 27 SDF links composed with the parallel-axis theorem by
+  // tools/hexa_params.py (total 2.7211 kg, CoG z = 0.04122 m; off-diagonals < 1e-14 dropped)
+  const double I[9] = {4.4024422324e-02, 0, 0, 0, 4.4059346318e-02, 0, 0, 0, 7.7083344191e-02};
+  std::memcpy(v->inertia, I, sizeof(I));
+  if (!invert(3, I, v->inv_inertia)) return false;
+  // rotor positions (FLU, m) and spin (custom_hexa_arm/model.sdf:653,769,882,995,1108,1221; plugins :1631-1733)
+  const double x[6] = {-0.255691, 0.255691, -0.255691, 0.255691, 0.0, 0.0};
+  const double y[6] = {0.1475, -0.1475, -0.1475, 0.1475, 0.295, -0.295};
+  const double sg[6] = {+1, -1, -1, +1, -1, +1};  // +1 cw, -1 ccw (reaction torque sign in z-up)
+  const double mc = 0.0168;                       // moment constant, m
+  double A[4 * 6];
+  for (int r = 0; r < 6; r++) { A[0 * 6 + r] = 1.0; A[1 * 6 + r] = y[r]; A[2 * 6 + r] = -x[r]; A[3 * 6 + r] = sg[r] * mc; }
+  std::memcpy(v->mix, A, sizeof(A));
+  if (!allocation_from_mix(6, A, v->alloc)) return false;
+  const double kf = 2.11e-5;  // N/(rad/s)^2 ; speed limits 150..820 rad/s (airframe/4022_*:64-76)
+  for (int r = 0; r < 6; r++) { v->t_min[r] = kf * 150.0 * 150.0; v->t_max[r] = kf * 820.0 * 820.0; }
+  v->moment_scale = 1.0;  // free parameter (no reference value): +-1 action = +-1 N m
+  return true;
+}
+
+template <typename T>
+Params<T> make_params(const amenv& e) {
+  const amenv_config& c = e.cfg;
+  const amenv_vehicle& v = c.vehicle;
+  Params<T> P;
+  std::memset(&P, 0, sizeof(P));
+  P.mass = T(v.mass); P.inv_mass = T(1.0 / v.mass); P.g = T(v.g);
+  for (int i = 0; i < 9; i++) { P.I[i] = T(v.inertia[i]); P.J[i] = T(v.inv_inertia[i]); }
+  for (int r = 0; r < v.n_rotors; r++) {
+    for (int j = 0; j < 4; j++) { P.alloc[r][j] = T(v.alloc[r * 4 + j]); P.mix[j][r] = T(v.mix[j * v.n_rotors + r]); }
+    P.tmin[r] = T(v.t_min[r]); P.tmax[r] = T(v.t_max[r]);
+  }
+  const int ns = c.task.rk4_substeps > 0 ? c.task.rk4_substeps : 1;
+  P.h = T(c.task.dt / ns);
+  P.mass_f = float(v.mass); P.g_f = float(v.g); P.mscale_f = float(v.moment_scale);
+  for (int k = 0; k < AMENV_MAX_WAYPOINTS; k++) { P.traj_sin[k] = float(c.task.traj_sin[k]); P.traj_cos[k] = float(c.task.traj_cos[k]); }
+  P.n_rotors = v.n_rotors; P.substeps = ns; P.K = c.task.num_waypoints;
+  P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit;
+  P.flags = c.flags;
+  P.seed_lo = uint32_t(c.seed); P.seed_hi = uint32_t(c.seed >> 32);
+  P.gid0 = c.env_id_offset;
+  P.n = c.num_envs; P.nf = e.nf;
+  return P;
+}
+
+int n_float_fields(const amenv_config* c) { return AMENV_F_WP0 + 3 * c->task.num_waypoints + 3 * c->vehicle.n_joints; }
+
+const char* validate(const amenv_config* c) {
+  if (!c) return "config is NULL";
+  if (c->struct_size != sizeof(amenv_config)) return "amenv_config.struct_size mismatch (ABI)";
+  if (c->abi_version != AMENV_ABI_VERSION) return "amenv_config.abi_version mismatch";
+  if (c->num_envs <= 0) return "num_envs must be > 0";
+  if (c->dtype != AMENV_F32 && c->dtype != AMENV_F64) return "dtype must be AMENV_F32 or AMENV_F64";
+  if (c->vehicle.n_rotors < 1 || c->vehicle.n_rotors > AMENV_MAX_ROTORS) return "n_rotors out of range";
+  if (c->vehicle.n_joints != 0) return "n_joints != 0 (arm) is not built in this version";
+  if (c->task.variant != AMENV_TASK_V2_SCALED20) return "task variant not built in this version";
+  if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
+  if (c->task.max_episode_steps < 1 || c->task.counter_limit < 0) return "bad episode limits";
+  if (!(c->task.dt > 0.0) || !(c->vehicle.mass > 0.0)) return "dt and mass must be positive";
+  if (c->block_size != 0 && c->block_size != 64 && c->block_size != 256) return "block_size must be 0, 64 or 256";
+  return nullptr;
+}
+
+template <typename T, int NROT>
+hipError_t launch_step(const amenv& e, const StepIO& io, hipStream_t s) {
+  const Params<T> P = make_params<T>(e);
+  const int n = e.cfg.num_envs;
+  if (e.block == 64) {
+    hipLaunchKernelGGL((step_kernel<T, NROT, 64>), dim3((n + 63) / 64), dim3(64), 0, s, P, (T*)e.fstate, e.istate, io);
+  } else {
+    hipLaunchKernelGGL((step_kernel<T, NROT, 256>), dim3((n + 255) / 256), dim3(256), 0, s, P, (T*)e.fstate, e.istate, io);
+  }
+  return hipGetLastError();
+}
+
+template <typename T, int NROT>
+hipError_t launch_rollout(const amenv& e, const StepIO& io, int T_steps, hipStream_t s) {
+  const Params<T> P = make_params<T>(e);
+  const int n = e.cfg.num_envs;
+  if (e.block == 64) {
+    hipLaunchKernelGGL((rollout_kernel<T, NROT, 64>), dim3((n + 63) / 64), dim3(64), 0, s, P, (T*)e.fstate, e.istate, io, T_steps);
+  } else {
+    hipLaunchKernelGGL((rollout_kernel<T, NROT, 256>), dim3((n + 255) / 256), dim3(256), 0, s, P, (T*)e.fstate, e.istate, io, T_steps);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s) {
+  const int nr = e.cfg.vehicle.n_rotors;
+  if (T_steps == 0) {
+    if (nr == 4) return launch_step<T, 4>(e, io, s);
+    if (nr == 6) return launch_step<T, 6>(e, io, s);
+    return launch_step<T, 0>(e, io, s);
+  }
+  if (nr == 4) return launch_rollout<T, 4>(e, io, T_steps, s);
+  if (nr == 6) return launch_rollout<T, 6>(e, io, T_steps, s);
+  return launch_rollout<T, 0>(e, io, T_steps, s);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+const char* amenv_version(void) { return "amenv 0.1 (gfx950, abi 1)"; }
+
+int amenv_default_config(const char* vehicle_name, int32_t num_envs, amenv_config* cfg) {
+  if (!cfg || !vehicle_name) return fail(nullptr, AMENV_ERR_INVALID, "amenv_default_config: NULL argument");
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->struct_size = uint32_t(sizeof(*cfg));
+  cfg->abi_version = AMENV_ABI_VERSION;
+  cfg->num_envs = num_envs;
+  cfg->dtype = AMENV_F32;
+  cfg->flags = AMENV_FLAG_AUTO_RESET;
+  cfg->block_size = 0;
+  cfg->seed = 0;
+  cfg->env_id_offset = 0;
+  bool ok;
+  if (!std::strcmp(vehicle_name, "quad")) ok = vehicle_quad(&cfg->vehicle);
+  else if (!std::strcmp(vehicle_name, "hexa")) ok = vehicle_hexa(&cfg->vehicle);
+  else return fail(nullptr, AMENV_ERR_INVALID, std::string("unknown vehicle '") + vehicle_name + "' (quad | hexa)");
+  if (!ok) return fail(nullptr, AMENV_ERR_INVALID, "singular vehicle matrices");
+  fill_task_defaults(&cfg->task, 1);
+  return AMENV_OK;
+}
+
+int amenv_dims(const amenv_config* cfg, int32_t* obs_dim, int32_t* act_dim, int32_t* nff, int32_t* nif) {
+  if (!cfg) return AMENV_ERR_INVALID;
+  if (obs_dim) *obs_dim = kObsDim;
+  if (act_dim) *act_dim = kActDim;
+  if (nff) *nff = n_float_fields(cfg);
+  if (nif) *nif = AMENV_I_NFIELDS;
+  return AMENV_OK;
+}
+
+// DESIGN.md "Algorithmic bytes": what one env-step of amenv_step() must move through HBM.
+int64_t amenv_bytes_per_env_step(const amenv_config* cfg) {
+  if (!cfg) return 0;
+  const int64_t ts = cfg->dtype == AMENV_F64 ? 8 : 4;
+  const int64_t K = cfg->task.num_waypoints;
+  const int64_t rd = ts * (13 /*state*/ + 1 /*final_yaw*/ + 1 /*last_distance*/ + 1 /*ep_return*/ + 3 * K /*waypoints*/) +
+                     4 * 3 /*step,counter,flags*/ + 4 * kActDim /*action*/;
+  const int64_t wr = ts * (13 + 1 + 1) + 4 * 3 + 4 * kObsDim /*obs*/ + ts /*reward*/ + 1 /*done*/ + 4 /*info*/;
+  return rd + wr;
+}
+
+int amenv_create(const amenv_config* cfg, int device, amenv** out) {
+  if (!out) return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: out is NULL");
+  *out = nullptr;
+  if (const char* why = validate(cfg)) return fail(nullptr, AMENV_ERR_INVALID, std::string("amenv_create: ") + why);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, AMENV_ERR_NO_DEVICE, "amenv_create: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: device index out of range");
+  hipDeviceProp_t prop;
+  AMENV_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, AMENV_ERR_NO_DEVICE, std::string("amenv_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  amenv* e = new (std::nothrow) amenv();
+  if (!e) return fail(nullptr, AMENV_ERR_ALLOC, "amenv_create: out of host memory");
+  e->cfg = *cfg;
+  e->device = device;
+  e->nf = n_float_fields(cfg);
+  const size_t n = size_t(cfg->num_envs), ts = cfg->dtype == AMENV_F64 ? 8 : 4;
+  e->fbytes = size_t(e->nf) * n * ts;
+  e->ibytes = size_t(AMENV_I_NFIELDS) * n * sizeof(int32_t);
+  // latency regime (few waves per CU): one wave per workgroup spreads the waves over more CUs;
+  // throughput regime: 256-thread workgroups
+  e->block = cfg->block_size ? cfg->block_size : (cfg->num_envs <= 65536 ? 64 : 256);
+  DeviceGuard g(device);
+  hipError_t s;
+  if ((s = hipMalloc(&e->fstate, e->fbytes)) != hipSuccess || (s = hipMalloc((void**)&e->istate, e->ibytes)) != hipSuccess ||
+      (s = hipMalloc((void**)&e->stats, sizeof(unsigned long long) * S_COUNT)) != hipSuccess ||
+      (s = hipMemset(e->fstate, 0, e->fbytes)) != hipSuccess || (s = hipMemset(e->istate, 0, e->ibytes)) != hipSuccess ||
+      (s = hipMemset(e->stats, 0, sizeof(unsigned long long) * S_COUNT)) != hipSuccess) {
+    std::string msg = std::string("amenv_create: device allocation failed: ") + hipGetErrorString(s);
+    amenv_destroy(e);
+    return fail(nullptr, AMENV_ERR_ALLOC, msg);
+  }
+  char buf[160];
+  std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,BS=%d>", cfg->dtype == AMENV_F64 ? "double" : "float",
+                (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : 0, e->block);
+  e->kname = buf;
+  *out = e;
+  return AMENV_OK;
+}
+
+int amenv_destroy(amenv* e) {
+  if (!e) return AMENV_OK;
+  {
+    DeviceGuard g(e->device);
+    if (e->fstate) (void)hipFree(e->fstate);
+    if (e->istate) (void)hipFree(e->istate);
+    if (e->stats) (void)hipFree(e->stats);
+  }
+  delete e;
+  return AMENV_OK;
+}
+
+const char* amenv_last_error(const amenv* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+const char* amenv_kernel_name(const amenv* e) { return e ? e->kname.c_str() : ""; }
+
+int amenv_reset(amenv* e, const uint8_t* mask, float* obs_out, void* stream) {
+  if (!e) return AMENV_ERR_INVALID;
+  DeviceGuard g(e->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int n = e->cfg.num_envs, bs = 256;
+  if (e->cfg.dtype == AMENV_F64) {
+    hipLaunchKernelGGL((reset_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<double>(*e), (double*)e->fstate, e->istate, mask, obs_out);
+  } else {
+    hipLaunchKernelGGL((reset_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<float>(*e), (float*)e->fstate, e->istate, mask, obs_out);
+  }
+  AMENV_HIP(e, hipGetLastError());
+  return AMENV_OK;
+}
+
+int amenv_observe(amenv* e, float* obs_out, void* stream) {
+  if (!e || !obs_out) return fail(e, AMENV_ERR_INVALID, "amenv_observe: NULL argument");
+  DeviceGuard g(e->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int n = e->cfg.num_envs, bs = 256;
+  if (e->cfg.dtype == AMENV_F64) {
+    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<double>(*e), (const double*)e->fstate, e->istate, obs_out);
+  } else {
+    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<float>(*e), (const float*)e->fstate, e->istate, obs_out);
+  }
+  AMENV_HIP(e, hipGetLastError());
+  return AMENV_OK;
+}
+
+int amenv_step(amenv* e, const float* actions, float* obs, void* reward, uint8_t* done, uint32_t* info_bits, float* terminal_obs,
+               float* ep_return, int32_t* ep_len, void* stream) {
+  if (!e) return AMENV_ERR_INVALID;
+  if (!actions || !obs || !reward || !done || !info_bits) return fail(e, AMENV_ERR_INVALID, "amenv_step: actions/obs/reward/done/info_bits must be non-NULL");
+  if (!aligned16(actions) || !aligned16(obs) || (terminal_obs && !aligned16(terminal_obs)))
+    return fail(e, AMENV_ERR_INVALID, "amenv_step: actions/obs/terminal_obs must be 16-byte aligned");
+  DeviceGuard g(e->device);
+  StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, terminal_obs, ep_return, ep_len, e->stats};
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, 0, s) : dispatch_step<float>(*e, io, 0, s);
+  AMENV_HIP(e, st);
+  e->steps += uint64_t(e->cfg.num_envs);
+  return AMENV_OK;
+}
+
+int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, void* reward, uint8_t* done, uint32_t* info_bits,
+                  void* stream) {
+  if (!e) return AMENV_ERR_INVALID;
+  if (n_steps <= 0 || !actions) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: n_steps must be > 0 and actions non-NULL");
+  if (!aligned16(actions) || (obs && !aligned16(obs))) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: actions/obs must be 16-byte aligned");
+  DeviceGuard g(e->device);
+  StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, nullptr, nullptr, nullptr, e->stats};
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, n_steps, s) : dispatch_step<float>(*e, io, n_steps, s);
+  AMENV_HIP(e, st);
+  e->steps += uint64_t(e->cfg.num_envs) * uint64_t(n_steps);
+  return AMENV_OK;
+}
+
+int amenv_get_state(amenv* e, void* fstate, int32_t* istate, void* stream) {
+  if (!e) return AMENV_ERR_INVALID;
+  DeviceGuard g(e->device);
+  if (fstate) AMENV_HIP(e, hipMemcpyAsync(fstate, e->fstate, e->fbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (istate) AMENV_HIP(e, hipMemcpyAsync(istate, e->istate, e->ibytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return AMENV_OK;
+}
+
+int amenv_set_state(amenv* e, const void* fstate, const int32_t* istate, void* stream) {
+  if (!e) return AMENV_ERR_INVALID;
+  DeviceGuard g(e->device);
+  if (fstate) AMENV_HIP(e, hipMemcpyAsync(e->fstate, fstate, e->fbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (istate) AMENV_HIP(e, hipMemcpyAsync(e->istate, istate, e->ibytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return AMENV_OK;
+}
+
+int amenv_stats_read(amenv* e, amenv_stats* out, int reset, void* stream) {
+  if (!e || !out) return fail(e, AMENV_ERR_INVALID, "amenv_stats_read: NULL argument");
+  DeviceGuard g(e->device);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long h[S_COUNT];
+  AMENV_HIP(e, hipMemcpyAsync(h, e->stats, sizeof(h), hipMemcpyDeviceToHost, s));
+  if (reset) AMENV_HIP(e, hipMemsetAsync(e->stats, 0, sizeof(h), s));
+  AMENV_HIP(e, hipStreamSynchronize(s));
+  out->steps = e->steps;
+  out->episodes = h[S_EPISODES]; out->terminated = h[S_TERMINATED]; out->truncated = h[S_TRUNCATED];
+  out->success = h[S_SUCCESS]; out->crashed = h[S_CRASHED]; out->oob = h[S_OOB]; out->nonfinite = h[S_NONFINITE];
+  out->length_sum = h[S_LENGTH]; out->return_sum_q10 = (int64_t)h[S_RETURN_Q10];
+  if (reset) e->steps = 0;
+  return AMENV_OK;
+}
+
+}  // extern "C"

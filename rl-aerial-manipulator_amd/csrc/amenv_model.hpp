@@ -1,0 +1,332 @@
+// amenv_model.hpp -- per-environment device code for gfx950 (CDNA4): everything one lane does
+// for one environment in one control step.  One lane = one environment; all of an
+// environment's episode state lives in that lane's registers for the whole step.
+//
+// Semantics follow the reference (paths relative to the reference root,
+// v2 = initial-implementation-v2):
+//   mixer / clamp / re-mix        v2/simul_files/model/quadcopter.py:105-112
+//   ODE right-hand side           v2/simul_files/model/quadcopter.py:66-103
+//   R(q/|q|) third column         v2/simul_files/utils/quaternion.py:46-77 (closed form)
+//   integrate + renormalise       v2/simul_files/model/quadcopter.py:113-114 (RK4 for odeint)
+//   reward                        v2/rl_env_scaledObs.py:198-231
+//   step state machine            v2/rl_env_scaledObs.py:135-196
+//   observation                   v2/rl_env_scaledObs.py:98-121
+//   quaternion -> roll/pitch/yaw  v2/utils2/utils.py:4-9
+//   reset + waypoint generators   v2/rl_env_scaledObs.py:40-79, v2/utils2/utils.py:12-95
+//
+// Templated on the arithmetic type T: float is the product path, double is the logic-check
+// build of the SAME code (tests compare it with the fp64 CPU oracle at ~1e-12).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/amenv.h"
+
+namespace amenv_dev {
+
+constexpr int kObsDim = 20;  // v2 observation
+constexpr int kActDim = 4;
+
+// ---- kernel-argument constants (uniform: live in SGPRs / scalar loads) -------------------
+template <typename T>
+struct Params {
+  T mass, inv_mass, g;
+  T I[9], J[9];                       // inertia, inverse inertia (row-major)
+  T alloc[AMENV_MAX_ROTORS][4];       // rotor thrusts = alloc . [F,Mx,My,Mz]
+  T mix[4][AMENV_MAX_ROTORS];         // [F,Mx,My,Mz] = mix . thrusts
+  T tmin[AMENV_MAX_ROTORS], tmax[AMENV_MAX_ROTORS];
+  T h;                                // dt / substeps
+  float mass_f, g_f, mscale_f;        // action scaling is fp32 in the reference (NumPy >= 2 promotion)
+  float traj_sin[AMENV_MAX_WAYPOINTS], traj_cos[AMENV_MAX_WAYPOINTS];
+  int32_t n_rotors, substeps, K, max_steps, counter_limit;
+  uint32_t flags;
+  uint32_t seed_lo, seed_hi;
+  int64_t gid0;                       // global id of local env 0
+  int32_t n;                          // envs on this device
+  int32_t nf;                         // float fields
+};
+
+// ---- math helpers: one definition per arithmetic type ------------------------------------
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp, 1 instr
+__device__ __forceinline__ double rcp_(double x) { return 1.0 / x; }
+__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }                  // correctly rounded
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float rsqrt_(float x) {                                     // v_rsq + one Newton step
+  float y = __builtin_amdgcn_rsqf(x);
+  return y * fmaf(-0.5f * x, y * y, 1.5f);
+}
+__device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float atan2_(float a, float b) { return atan2f(a, b); }
+__device__ __forceinline__ double atan2_(double a, double b) { return atan2(a, b); }
+__device__ __forceinline__ float asin_(float a) { return asinf(a); }
+__device__ __forceinline__ double asin_(double a) { return asin(a); }
+__device__ __forceinline__ float abs_(float a) { return fabsf(a); }
+__device__ __forceinline__ double abs_(double a) { return fabs(a); }
+__device__ __forceinline__ bool finite_(float a) { return __builtin_isfinite(a); }
+__device__ __forceinline__ bool finite_(double a) { return __builtin_isfinite(a); }
+
+// ---- per-env registers ------------------------------------------------------------------------
+template <typename T>
+struct Env {
+  T px, py, pz, vx, vy, vz, qw, qx, qy, qz, wx, wy, wz;
+  T wp[AMENV_MAX_WAYPOINTS][3];
+  T final_yaw, last_distance, ep_return;
+  int32_t step, counter, flags, episode;
+};
+
+template <typename T>
+struct Deriv { T vx, vy, vz, ax, ay, az, dqw, dqx, dqy, dqz, dwx, dwy, dwz; };
+
+// ODE right-hand side (quadcopter.py:66-103).  F, M: post-mixer wrench, constant over the step.
+template <typename T>
+__device__ __forceinline__ Deriv<T> rhs(const Params<T>& P, T vx, T vy, T vz, T qw, T qx, T qy, T qz, T p, T q, T r, T Fm,
+                                        T Mx, T My, T Mz) {
+  Deriv<T> d;
+  // third column of wRb for the NORMALISED quaternion: quadratic in q/|q| => divide by |q|^2 once
+  const T n2 = qw * qw + qx * qx + qy * qy + qz * qz;
+  const T in2 = rcp_(n2);
+  const T s = (Fm + Fm) * in2;                       // 2 F / (m |q|^2)
+  d.vx = vx; d.vy = vy; d.vz = vz;                   // :89-91
+  d.ax = s * (qx * qz - qw * qy);                    // :73-74
+  d.ay = s * (qy * qz + qw * qx);
+  d.az = (Fm - s * (qx * qx + qy * qy)) - P.g;
+  // qdot = -1/2 Omega(p,q,r) q + 2 (1-|q|^2) q      :77-82
+  const T k = T(2) * (T(1) - n2);
+  d.dqw = T(0.5) * (p * qx + q * qy + r * qz) + k * qw;
+  d.dqx = T(-0.5) * (p * qw - r * qy + q * qz) + k * qx;
+  d.dqy = T(-0.5) * (q * qw + r * qx - p * qz) + k * qy;
+  d.dqz = T(-0.5) * (r * qw - q * qx + p * qy) + k * qz;
+  // pqrdot = invI (M - w x (I w))                   :86-87
+  const T i0 = P.I[0] * p + P.I[1] * q + P.I[2] * r;
+  const T i1 = P.I[3] * p + P.I[4] * q + P.I[5] * r;
+  const T i2 = P.I[6] * p + P.I[7] * q + P.I[8] * r;
+  const T t0 = Mx - (q * i2 - r * i1);
+  const T t1 = My - (r * i0 - p * i2);
+  const T t2 = Mz - (p * i1 - q * i0);
+  d.dwx = P.J[0] * t0 + P.J[1] * t1 + P.J[2] * t2;
+  d.dwy = P.J[3] * t0 + P.J[4] * t1 + P.J[5] * t2;
+  d.dwz = P.J[6] * t0 + P.J[7] * t1 + P.J[8] * t2;
+  return d;
+}
+
+// Quadcopter.update (quadcopter.py:105-114) with RK4 in place of odeint.
+template <typename T, int NROT>
+__device__ __forceinline__ void dynamics(const Params<T>& P, Env<T>& e, float a0, float a1, float a2, float a3) {
+  // action scaling in fp32, left to right (rl_env_scaledObs.py:125-126)
+  const float Ff = __fmul_rn(__fmul_rn(a0, P.mass_f), P.g_f);
+  const T u0 = T(Ff), u1 = T(__fmul_rn(a1, P.mscale_f)), u2 = T(__fmul_rn(a2, P.mscale_f)), u3 = T(__fmul_rn(a3, P.mscale_f));
+  // mixer -> per-rotor clamp -> re-mix (:109-112)
+  constexpr int NR = NROT > 0 ? NROT : AMENV_MAX_ROTORS;
+  T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    if (NROT == 0 && r >= P.n_rotors) break;
+    T t = P.alloc[r][0] * u0 + P.alloc[r][1] * u1 + P.alloc[r][2] * u2 + P.alloc[r][3] * u3;
+    t = t < P.tmax[r] ? t : P.tmax[r];
+    t = t > P.tmin[r] ? t : P.tmin[r];
+    F += P.mix[0][r] * t; Mx += P.mix[1][r] * t; My += P.mix[2][r] * t; Mz += P.mix[3][r] * t;
+  }
+  const T Fm = F * P.inv_mass;
+  const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+  for (int it = 0; it < P.substeps; it++) {
+    const Deriv<T> k1 = rhs(P, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz, Fm, Mx, My, Mz);
+    const Deriv<T> k2 = rhs(P, e.vx + hh * k1.ax, e.vy + hh * k1.ay, e.vz + hh * k1.az, e.qw + hh * k1.dqw, e.qx + hh * k1.dqx,
+                            e.qy + hh * k1.dqy, e.qz + hh * k1.dqz, e.wx + hh * k1.dwx, e.wy + hh * k1.dwy, e.wz + hh * k1.dwz, Fm, Mx,
+                            My, Mz);
+    const Deriv<T> k3 = rhs(P, e.vx + hh * k2.ax, e.vy + hh * k2.ay, e.vz + hh * k2.az, e.qw + hh * k2.dqw, e.qx + hh * k2.dqx,
+                            e.qy + hh * k2.dqy, e.qz + hh * k2.dqz, e.wx + hh * k2.dwx, e.wy + hh * k2.dwy, e.wz + hh * k2.dwz, Fm, Mx,
+                            My, Mz);
+    const Deriv<T> k4 = rhs(P, e.vx + h * k3.ax, e.vy + h * k3.ay, e.vz + h * k3.az, e.qw + h * k3.dqw, e.qx + h * k3.dqx,
+                            e.qy + h * k3.dqy, e.qz + h * k3.dqz, e.wx + h * k3.dwx, e.wy + h * k3.dwy, e.wz + h * k3.dwz, Fm, Mx, My,
+                            Mz);
+#define AMENV_RK4(x, f) e.x += h6 * (k1.f + T(2) * k2.f + T(2) * k3.f + k4.f)
+    AMENV_RK4(px, vx); AMENV_RK4(py, vy); AMENV_RK4(pz, vz);
+    AMENV_RK4(vx, ax); AMENV_RK4(vy, ay); AMENV_RK4(vz, az);
+    AMENV_RK4(qw, dqw); AMENV_RK4(qx, dqx); AMENV_RK4(qy, dqy); AMENV_RK4(qz, dqz);
+    AMENV_RK4(wx, dwx); AMENV_RK4(wy, dwy); AMENV_RK4(wz, dwz);
+#undef AMENV_RK4
+  }
+  const T rn = rsqrt_(e.qw * e.qw + e.qx * e.qx + e.qy * e.qy + e.qz * e.qz);   // :114
+  e.qw *= rn; e.qx *= rn; e.qy *= rn; e.qz *= rn;
+}
+
+template <typename T>
+__device__ __forceinline__ void current_waypoint(const Params<T>& P, const Env<T>& e, int idx, T& cx, T& cy, T& cz) {
+  cx = e.wp[0][0]; cy = e.wp[0][1]; cz = e.wp[0][2];
+#pragma unroll
+  for (int k = 1; k < AMENV_MAX_WAYPOINTS; k++)
+    if (k < P.K && idx >= k) { cx = e.wp[k][0]; cy = e.wp[k][1]; cz = e.wp[k][2]; }
+}
+
+// _get_observation (rl_env_scaledObs.py:98-121)
+template <typename T>
+__device__ __forceinline__ void observe(const Params<T>& P, const Env<T>& e, float* o) {
+  const int idx = e.flags & 255;
+  T cx, cy, cz;
+  current_waypoint(P, e, idx, cx, cy, cz);
+  o[0] = float(e.px / T(10)); o[1] = float(e.py / T(10)); o[2] = float(e.pz / T(10));
+  o[3] = float(e.vx / T(5)); o[4] = float(e.vy / T(5)); o[5] = float(e.vz / T(5));
+  o[6] = float(e.qw); o[7] = float(e.qx); o[8] = float(e.qy); o[9] = float(e.qz);
+  o[10] = float(e.wx / T(5)); o[11] = float(e.wy / T(5)); o[12] = float(e.wz / T(5));
+  o[13] = float((cx - e.px) / T(2)); o[14] = float((cy - e.py) / T(2)); o[15] = float((cz - e.pz) / T(2));
+  T nx = T(0), ny = T(0), nz = T(0);
+#pragma unroll
+  for (int k = 1; k < AMENV_MAX_WAYPOINTS; k++)
+    if (k < P.K && idx == k - 1) { nx = e.wp[k][0] - cx; ny = e.wp[k][1] - cy; nz = e.wp[k][2] - cz; }
+  o[16] = float(nx / T(2)); o[17] = float(ny / T(2)); o[18] = float(nz / T(2));
+  o[19] = float(e.final_yaw / T(3.14159265358979323846));
+}
+
+// One WaypointQuadEnv.step (rl_env_scaledObs.py:123-196) after the dynamics update.
+// Returns info bits; reward in `reward`.  Mutates the episode registers.
+template <typename T>
+__device__ __forceinline__ uint32_t task_step(const Params<T>& P, Env<T>& e, T& reward) {
+  uint32_t bits = 0;
+  int idx = e.flags & 255;
+  bool fwr = (e.flags & AMENV_FLAGBIT_FWR) != 0;
+  bool cact = (e.flags & AMENV_FLAGBIT_COUNTER_ACTIVE) != 0;
+  const bool truncated = e.step >= P.max_steps;                         // :144
+  e.step += 1;                                                          // :145
+  if (truncated) bits |= AMENV_INFO_TRUNCATED;
+
+  if (P.flags & AMENV_FLAG_NAN_GUARD) {                                 // deviation, see DESIGN.md
+    const T sum = e.px + e.py + e.pz + e.vx + e.vy + e.vz + e.qw + e.qx + e.qy + e.qz + e.wx + e.wy + e.wz;
+    if (!finite_(sum)) { reward = T(-100); return bits | AMENV_INFO_TERMINATED | AMENV_INFO_NONFINITE; }
+  }
+  T cx, cy, cz;
+  current_waypoint(P, e, idx, cx, cy, cz);
+  // ---- _calculate_reward (:198-231)
+  const T dx = e.px - cx, dy = e.py - cy, dz = e.pz - cz;
+  const T dist = sqrt_(dx * dx + dy * dy + dz * dz);                    // :204
+  T r_dist = T(-10) * dist;                                             // :207
+  const T v2 = e.vx * e.vx + e.vy * e.vy + e.vz * e.vz;
+  const T w2 = e.wx * e.wx + e.wy * e.wy + e.wz * e.wz;
+  const T vn = sqrt_(v2), wn = sqrt_(w2);
+  T r_speed = T(-0.1) * v2;                                             // :208
+  if (wn > T(0.1)) r_speed -= T(0.01) * w2;                             // :209-210
+  T r_time = T(-0.1);                                                   // :211
+  T r_prog = T(0);
+  if (e.last_distance >= T(0)) {                                        // :214-220
+    r_prog = T(20) * (e.last_distance - dist);
+    if (r_prog > T(0)) r_prog += T(2);
+  }
+  e.last_distance = dist;                                               // :222
+  if (fwr) {                                                            // :224-228
+    r_prog = T(0); r_time = T(0);
+    if (dist < T(0.1)) r_dist = T(1);
+  }
+  reward = ((r_dist + r_speed) + r_time) + r_prog;                      // :231
+
+  bool returned = false;
+  if (dist < T(0.1)) {                                                  // :147
+    if (!fwr) { idx += 1; reward += T(100); }                           // :148-150
+    if (idx >= P.K) {                                                   // :153 (else: next waypoint, fall through)
+      idx = P.K;                                                        // waypoint_index == len(list)
+      // roll, pitch, yaw (utils2/utils.py:4-9 closed form); only the hold-phase bonuses use them
+      const T roll = atan2_(T(2) * (e.qw * e.qx + e.qy * e.qz), T(1) - T(2) * (e.qx * e.qx + e.qy * e.qy));
+      T sp = T(2) * (e.qw * e.qy - e.qz * e.qx);
+      sp = sp > T(1) ? T(1) : (sp < T(-1) ? T(-1) : sp);
+      const T pitch = asin_(sp);
+      const T yaw = atan2_(T(2) * (e.qw * e.qz + e.qx * e.qy), T(1) - T(2) * (e.qy * e.qy + e.qz * e.qz));
+      const T two_pi = T(6.28318530717958647692);
+      const T dyaw = abs_(yaw - e.final_yaw);
+      bits |= AMENV_INFO_SUCCESS;
+      if (vn < T(0.1) && wn < T(0.1)) bits |= AMENV_INFO_STOPPED;
+      if (!fwr) {                                                       // :156-164 first arrival
+        cact = true; fwr = true;
+        const T stop_b = vn < T(1) ? T(150) * (T(1) - v2) : T(0);
+        const T yaw_b = dyaw < two_pi ? T(100) * (T(1) - dyaw / two_pi) : T(0);
+        reward = ((reward + T(200)) + stop_b) + yaw_b;
+      } else {                                                          // :165-179 holding
+        const T yaw_b = dyaw < two_pi ? T(30) * (T(1) - dyaw / two_pi) : T(0);
+        const T ar = abs_(roll), ap = abs_(pitch);
+        const T roll_b = ar < T(0.2) ? T(10) * (T(1) - ar / T(0.2)) : T(-0.1) * ar;
+        const T pitch_b = ap < T(0.2) ? T(10) * (T(1) - ap / T(0.2)) : T(-0.1) * ap;
+        reward = ((reward + yaw_b) + roll_b) + pitch_b;
+        if (e.counter <= P.counter_limit) e.counter += 1;               // :166-167
+        else bits |= AMENV_INFO_TERMINATED;                             // :174-179
+      }
+      returned = true;
+    }
+  }
+  if (!returned) {
+    if (cact) e.counter += 1;                                           // :181-182
+    if (e.pz < T(0.1)) {                                                // :188-192
+      reward -= T(100);
+      if (e.vz < T(0)) reward += e.vz * T(100);
+      bits |= AMENV_INFO_TERMINATED | AMENV_INFO_CRASHED;
+    } else if (sqrt_(e.px * e.px + e.py * e.py + e.pz * e.pz) > T(10)) { // :193-195
+      reward -= T(100);
+      bits |= AMENV_INFO_TERMINATED | AMENV_INFO_OOB;
+    }
+  }
+  e.flags = (idx & 255) | (fwr ? AMENV_FLAGBIT_FWR : 0) | (cact ? AMENV_FLAGBIT_COUNTER_ACTIVE : 0);
+  return bits;
+}
+
+// ---- counter-based reset RNG: Philox4x32-10, key = seed, counter = (global env id, episode, block)
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return float(r >> 8) * 5.9604644775390625e-08f; }
+
+// WaypointQuadEnv.reset (rl_env_scaledObs.py:40-79) with the DESIGN.md draw table.  All draws
+// are formed in fp32 with explicit fmaf so the CPU oracle reproduces them bit for bit.
+template <typename T>
+__device__ __forceinline__ void reset_env(const Params<T>& P, Env<T>& e, int64_t gid) {
+  uint32_t r[12];
+#pragma unroll
+  for (uint32_t b = 0; b < 3; b++)
+    philox4x32_10(P.seed_lo, P.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(e.episode), b, &r[4 * b]);
+  const float PIF = 3.14159274101257324f;
+  const float sx = fmaf(2.0f, u01(r[0]), -1.0f);                        // :44
+  const float sy = fmaf(2.0f, u01(r[1]), -1.0f);
+  const float sz = fmaf(1.0f, u01(r[3]), 1.0f);                         // :45
+  const float sel0 = u01(r[4]), sel1 = u01(r[5]);                       // :63,65
+  const float ex = fmaf(2.0f, u01(r[6]), -1.0f);                        // utils2/utils.py:15-16
+  const float ey = fmaf(2.0f, u01(r[7]), -1.0f);
+  const float ez = fmaf(2.5f, u01(r[9]), 0.5f);
+  const uint32_t axis = r[10] % 3u;                                     // utils2/utils.py:32
+  const float fyaw = fmaf(2.0f * PIF, u01(r[11]), -PIF);                // :72
+  const int kind = sel0 < 0.3f ? 0 : (sel1 < 0.6f ? 1 : 2);
+#pragma unroll
+  for (int k = 1; k <= AMENV_MAX_WAYPOINTS; k++) {
+    if (k > P.K) break;
+    float wx, wy, wz;
+    if (kind == 2) {                                                    // helical, utils2/utils.py:61-95
+      wx = fmaf(0.8f, P.traj_cos[k - 1], sx);
+      wy = fmaf(0.8f, P.traj_sin[k - 1], sy);
+      wz = fmaxf(fmaf(float(k), 0.4f, sz), 0.2f);
+    } else {                                                            // linear / curved, :12-57
+      const float t = __fdiv_rn(float(k), float(P.K));
+      wx = fmaf(t, __fsub_rn(ex, sx), sx); wy = fmaf(t, __fsub_rn(ey, sy), sy); wz = fmaf(t, __fsub_rn(ez, sz), sz);
+      if (kind == 1) {
+        const float s = P.traj_sin[k - 1];
+        if (axis == 0) wz = __fadd_rn(wz, s); else if (axis == 1) wy = __fadd_rn(wy, s); else wx = __fadd_rn(wx, s);
+        wz = fmaxf(wz, 0.2f);
+      }
+    }
+    e.wp[k - 1][0] = T(wx); e.wp[k - 1][1] = T(wy); e.wp[k - 1][2] = T(wz);
+  }
+  e.px = T(sx); e.py = T(sy); e.pz = T(sz);
+  e.vx = e.vy = e.vz = T(0);
+  e.qw = T(1); e.qx = e.qy = e.qz = T(0);                               // quadcopter.py:28-38, attitude (0,0,0)
+  e.wx = e.wy = e.wz = T(0);
+  e.final_yaw = T(fyaw);
+  e.last_distance = T(-1);                                              // :76 None
+  e.ep_return = T(0);
+  e.step = 0; e.counter = 0; e.flags = 0;                               // :55-59,74-77
+  e.episode += 1;
+}
+
+}  // namespace amenv_dev
