@@ -206,6 +206,14 @@ int amenv_reset(amenv* env, const uint8_t* mask, float* obs_out, void* stream);
 int amenv_step(amenv* env, const float* actions, float* obs, void* reward, uint8_t* done,
                uint32_t* info_bits, float* terminal_obs, float* ep_return, int32_t* ep_len, void* stream);
 
+/* amenv_step() plus the device-side duration of that one kernel: the launch carries start/stop
+ * events stamped by the kernel's own dispatch (hipExtLaunchKernelGGL), then the call WAITS for the
+ * stop event and writes the elapsed microseconds to *kernel_us (host pointer).  For bench/profiling
+ * only: it synchronises. */
+int amenv_step_timed(amenv* env, const float* actions, float* obs, void* reward, uint8_t* done,
+                     uint32_t* info_bits, float* terminal_obs, float* ep_return, int32_t* ep_len, void* stream,
+                     float* kernel_us);
+
 /* T consecutive steps in ONE launch with open-loop actions [T,N,act_dim] (action replay /
  * action repeat).  Per-step outputs are [T,N,...] or NULL; state stays in registers between
  * steps.  Same per-step semantics as amenv_step (including auto-reset). */

@@ -67,6 +67,7 @@ SYMBOLS = {
     "amenv_last_error": (C.c_char_p, [_P]),
     "amenv_reset": (C.c_int, [_P, _P, _P, _P]),
     "amenv_step": (C.c_int, [_P] * 10),
+    "amenv_step_timed": (C.c_int, [_P] * 10 + [C.POINTER(C.c_float)]),
     "amenv_rollout": (C.c_int, [_P, C.c_int32] + [_P] * 6),
     "amenv_get_state": (C.c_int, [_P] * 4),
     "amenv_set_state": (C.c_int, [_P] * 4),

@@ -3,6 +3,7 @@
 // instantiation (arithmetic type x rotor count x workgroup size) and enqueues it on the
 // caller's stream.  No synchronisation and no allocation after amenv_create().
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -24,6 +25,7 @@ struct amenv {
   size_t fbytes = 0, ibytes = 0;
   int block = 64;
   uint64_t steps = 0;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // amenv_step_timed only
   std::string err;
   std::string kname;
 };
@@ -184,10 +186,16 @@ const char* validate(const amenv_config* c) {
 }
 
 template <typename T, int NROT>
-hipError_t launch_step(const amenv& e, const StepIO& io, hipStream_t s) {
+hipError_t launch_step(const amenv& e, const StepIO& io, hipStream_t s, bool timed) {
   const Params<T> P = make_params<T>(e);
   const int n = e.cfg.num_envs;
-  if (e.block == 64) {
+  if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
+    if (e.block == 64) {
+      hipExtLaunchKernelGGL((step_kernel<T, NROT, 64>), dim3((n + 63) / 64), dim3(64), 0, s, e.ev_start, e.ev_stop, 0, P, (T*)e.fstate, e.istate, io);
+    } else {
+      hipExtLaunchKernelGGL((step_kernel<T, NROT, 256>), dim3((n + 255) / 256), dim3(256), 0, s, e.ev_start, e.ev_stop, 0, P, (T*)e.fstate, e.istate, io);
+    }
+  } else if (e.block == 64) {
     hipLaunchKernelGGL((step_kernel<T, NROT, 64>), dim3((n + 63) / 64), dim3(64), 0, s, P, (T*)e.fstate, e.istate, io);
   } else {
     hipLaunchKernelGGL((step_kernel<T, NROT, 256>), dim3((n + 255) / 256), dim3(256), 0, s, P, (T*)e.fstate, e.istate, io);
@@ -208,12 +216,12 @@ hipError_t launch_rollout(const amenv& e, const StepIO& io, int T_steps, hipStre
 }
 
 template <typename T>
-hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s) {
+hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed = false) {
   const int nr = e.cfg.vehicle.n_rotors;
   if (T_steps == 0) {
-    if (nr == 4) return launch_step<T, 4>(e, io, s);
-    if (nr == 6) return launch_step<T, 6>(e, io, s);
-    return launch_step<T, 0>(e, io, s);
+    if (nr == 4) return launch_step<T, 4>(e, io, s, timed);
+    if (nr == 6) return launch_step<T, 6>(e, io, s, timed);
+    return launch_step<T, 0>(e, io, s, timed);
   }
   if (nr == 4) return launch_rollout<T, 4>(e, io, T_steps, s);
   if (nr == 6) return launch_rollout<T, 6>(e, io, T_steps, s);
@@ -316,6 +324,8 @@ int amenv_destroy(amenv* e) {
     if (e->fstate) (void)hipFree(e->fstate);
     if (e->istate) (void)hipFree(e->istate);
     if (e->stats) (void)hipFree(e->stats);
+    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
   }
   delete e;
   return AMENV_OK;
@@ -363,6 +373,26 @@ int amenv_step(amenv* e, const float* actions, float* obs, void* reward, uint8_t
   hipStream_t s = (hipStream_t)stream;
   hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, 0, s) : dispatch_step<float>(*e, io, 0, s);
   AMENV_HIP(e, st);
+  e->steps += uint64_t(e->cfg.num_envs);
+  return AMENV_OK;
+}
+
+int amenv_step_timed(amenv* e, const float* actions, float* obs, void* reward, uint8_t* done, uint32_t* info_bits,
+                     float* terminal_obs, float* ep_return, int32_t* ep_len, void* stream, float* kernel_us) {
+  if (!e) return AMENV_ERR_INVALID;
+  if (!actions || !obs || !reward || !done || !info_bits || !kernel_us) return fail(e, AMENV_ERR_INVALID, "amenv_step_timed: NULL argument");
+  if (!aligned16(actions) || !aligned16(obs) || (terminal_obs && !aligned16(terminal_obs)))
+    return fail(e, AMENV_ERR_INVALID, "amenv_step_timed: actions/obs/terminal_obs must be 16-byte aligned");
+  DeviceGuard g(e->device);
+  if (!e->ev_start) { AMENV_HIP(e, hipEventCreate(&e->ev_start)); AMENV_HIP(e, hipEventCreate(&e->ev_stop)); }
+  StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, terminal_obs, ep_return, ep_len, e->stats};
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, 0, s, true) : dispatch_step<float>(*e, io, 0, s, true);
+  AMENV_HIP(e, st);
+  AMENV_HIP(e, hipEventSynchronize(e->ev_stop));
+  float ms = 0.f;
+  AMENV_HIP(e, hipEventElapsedTime(&ms, e->ev_start, e->ev_stop));
+  *kernel_us = ms * 1000.0f;
   e->steps += uint64_t(e->cfg.num_envs);
   return AMENV_OK;
 }

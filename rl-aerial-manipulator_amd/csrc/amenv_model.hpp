@@ -53,7 +53,7 @@ __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }            
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float rsqrt_(float x) {                                     // v_rsq + one Newton step
   float y = __builtin_amdgcn_rsqf(x);
-  return y * fmaf(-0.5f * x, y * y, 1.5f);
+  return y * __builtin_fmaf(-0.5f * x, y * y, 1.5f);
 }
 __device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ float atan2_(float a, float b) { return atan2f(a, b); }
@@ -77,35 +77,42 @@ struct Env {
 template <typename T>
 struct Deriv { T vx, vy, vz, ax, ay, az, dqw, dqx, dqy, dqz, dwx, dwy, dwz; };
 
+// All floating-point contraction is explicit: the library is compiled with -ffp-contract=off and every
+// fused multiply-add below is written as fma_().  The step kernel, the rollout kernel and any future
+// variant therefore produce bit-identical trajectories (tests/test_gpu_parity.py::test_rollout_*).
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T> __device__ __forceinline__ T dot3_(T a0, T a1, T a2, T b0, T b1, T b2) { return fma_(a0, b0, fma_(a1, b1, a2 * b2)); }
+
 // ODE right-hand side (quadcopter.py:66-103).  F, M: post-mixer wrench, constant over the step.
 template <typename T>
 __device__ __forceinline__ Deriv<T> rhs(const Params<T>& P, T vx, T vy, T vz, T qw, T qx, T qy, T qz, T p, T q, T r, T Fm,
                                         T Mx, T My, T Mz) {
   Deriv<T> d;
   // third column of wRb for the NORMALISED quaternion: quadratic in q/|q| => divide by |q|^2 once
-  const T n2 = qw * qw + qx * qx + qy * qy + qz * qz;
+  const T n2 = fma_(qw, qw, fma_(qx, qx, fma_(qy, qy, qz * qz)));
   const T in2 = rcp_(n2);
-  const T s = (Fm + Fm) * in2;                       // 2 F / (m |q|^2)
-  d.vx = vx; d.vy = vy; d.vz = vz;                   // :89-91
-  d.ax = s * (qx * qz - qw * qy);                    // :73-74
-  d.ay = s * (qy * qz + qw * qx);
-  d.az = (Fm - s * (qx * qx + qy * qy)) - P.g;
-  // qdot = -1/2 Omega(p,q,r) q + 2 (1-|q|^2) q      :77-82
-  const T k = T(2) * (T(1) - n2);
-  d.dqw = T(0.5) * (p * qx + q * qy + r * qz) + k * qw;
-  d.dqx = T(-0.5) * (p * qw - r * qy + q * qz) + k * qx;
-  d.dqy = T(-0.5) * (q * qw + r * qx - p * qz) + k * qy;
-  d.dqz = T(-0.5) * (r * qw - q * qx + p * qy) + k * qz;
-  // pqrdot = invI (M - w x (I w))                   :86-87
-  const T i0 = P.I[0] * p + P.I[1] * q + P.I[2] * r;
-  const T i1 = P.I[3] * p + P.I[4] * q + P.I[5] * r;
-  const T i2 = P.I[6] * p + P.I[7] * q + P.I[8] * r;
-  const T t0 = Mx - (q * i2 - r * i1);
-  const T t1 = My - (r * i0 - p * i2);
-  const T t2 = Mz - (p * i1 - q * i0);
-  d.dwx = P.J[0] * t0 + P.J[1] * t1 + P.J[2] * t2;
-  d.dwy = P.J[3] * t0 + P.J[4] * t1 + P.J[5] * t2;
-  d.dwz = P.J[6] * t0 + P.J[7] * t1 + P.J[8] * t2;
+  const T s = (Fm + Fm) * in2;                                   // 2 F / (m |q|^2)
+  d.vx = vx; d.vy = vy; d.vz = vz;                               // :89-91
+  d.ax = s * fma_(qx, qz, -(qw * qy));                           // :73-74
+  d.ay = s * fma_(qy, qz, qw * qx);
+  d.az = fma_(-s, fma_(qx, qx, qy * qy), Fm) - P.g;
+  // qdot = -1/2 Omega(p,q,r) q + 2 (1-|q|^2) q                  :77-82
+  const T k = fma_(T(-2), n2, T(2));
+  d.dqw = fma_(T(0.5), fma_(p, qx, fma_(q, qy, r * qz)), k * qw);
+  d.dqx = fma_(T(-0.5), fma_(p, qw, fma_(q, qz, -(r * qy))), k * qx);
+  d.dqy = fma_(T(-0.5), fma_(q, qw, fma_(r, qx, -(p * qz))), k * qy);
+  d.dqz = fma_(T(-0.5), fma_(r, qw, fma_(p, qy, -(q * qx))), k * qz);
+  // pqrdot = invI (M - w x (I w))                               :86-87
+  const T i0 = dot3_(P.I[0], P.I[1], P.I[2], p, q, r);
+  const T i1 = dot3_(P.I[3], P.I[4], P.I[5], p, q, r);
+  const T i2 = dot3_(P.I[6], P.I[7], P.I[8], p, q, r);
+  const T t0 = Mx - fma_(q, i2, -(r * i1));
+  const T t1 = My - fma_(r, i0, -(p * i2));
+  const T t2 = Mz - fma_(p, i1, -(q * i0));
+  d.dwx = dot3_(P.J[0], P.J[1], P.J[2], t0, t1, t2);
+  d.dwy = dot3_(P.J[3], P.J[4], P.J[5], t0, t1, t2);
+  d.dwz = dot3_(P.J[6], P.J[7], P.J[8], t0, t1, t2);
   return d;
 }
 
@@ -113,40 +120,41 @@ __device__ __forceinline__ Deriv<T> rhs(const Params<T>& P, T vx, T vy, T vz, T 
 template <typename T, int NROT>
 __device__ __forceinline__ void dynamics(const Params<T>& P, Env<T>& e, float a0, float a1, float a2, float a3) {
   // action scaling in fp32, left to right (rl_env_scaledObs.py:125-126)
-  const float Ff = __fmul_rn(__fmul_rn(a0, P.mass_f), P.g_f);
-  const T u0 = T(Ff), u1 = T(__fmul_rn(a1, P.mscale_f)), u2 = T(__fmul_rn(a2, P.mscale_f)), u3 = T(__fmul_rn(a3, P.mscale_f));
+  const float Ff = (a0 * P.mass_f) * P.g_f;
+  const T u0 = T(Ff), u1 = T(a1 * P.mscale_f), u2 = T(a2 * P.mscale_f), u3 = T(a3 * P.mscale_f);
   // mixer -> per-rotor clamp -> re-mix (:109-112)
   constexpr int NR = NROT > 0 ? NROT : AMENV_MAX_ROTORS;
   T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     if (NROT == 0 && r >= P.n_rotors) break;
-    T t = P.alloc[r][0] * u0 + P.alloc[r][1] * u1 + P.alloc[r][2] * u2 + P.alloc[r][3] * u3;
+    T t = fma_(P.alloc[r][0], u0, fma_(P.alloc[r][1], u1, fma_(P.alloc[r][2], u2, P.alloc[r][3] * u3)));
     t = t < P.tmax[r] ? t : P.tmax[r];
     t = t > P.tmin[r] ? t : P.tmin[r];
-    F += P.mix[0][r] * t; Mx += P.mix[1][r] * t; My += P.mix[2][r] * t; Mz += P.mix[3][r] * t;
+    F = fma_(P.mix[0][r], t, F); Mx = fma_(P.mix[1][r], t, Mx); My = fma_(P.mix[2][r], t, My); Mz = fma_(P.mix[3][r], t, Mz);
   }
   const T Fm = F * P.inv_mass;
   const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
   for (int it = 0; it < P.substeps; it++) {
     const Deriv<T> k1 = rhs(P, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz, Fm, Mx, My, Mz);
-    const Deriv<T> k2 = rhs(P, e.vx + hh * k1.ax, e.vy + hh * k1.ay, e.vz + hh * k1.az, e.qw + hh * k1.dqw, e.qx + hh * k1.dqx,
-                            e.qy + hh * k1.dqy, e.qz + hh * k1.dqz, e.wx + hh * k1.dwx, e.wy + hh * k1.dwy, e.wz + hh * k1.dwz, Fm, Mx,
-                            My, Mz);
-    const Deriv<T> k3 = rhs(P, e.vx + hh * k2.ax, e.vy + hh * k2.ay, e.vz + hh * k2.az, e.qw + hh * k2.dqw, e.qx + hh * k2.dqx,
-                            e.qy + hh * k2.dqy, e.qz + hh * k2.dqz, e.wx + hh * k2.dwx, e.wy + hh * k2.dwy, e.wz + hh * k2.dwz, Fm, Mx,
-                            My, Mz);
-    const Deriv<T> k4 = rhs(P, e.vx + h * k3.ax, e.vy + h * k3.ay, e.vz + h * k3.az, e.qw + h * k3.dqw, e.qx + h * k3.dqx,
-                            e.qy + h * k3.dqy, e.qz + h * k3.dqz, e.wx + h * k3.dwx, e.wy + h * k3.dwy, e.wz + h * k3.dwz, Fm, Mx, My,
-                            Mz);
-#define AMENV_RK4(x, f) e.x += h6 * (k1.f + T(2) * k2.f + T(2) * k3.f + k4.f)
+    const Deriv<T> k2 = rhs(P, fma_(hh, k1.ax, e.vx), fma_(hh, k1.ay, e.vy), fma_(hh, k1.az, e.vz), fma_(hh, k1.dqw, e.qw),
+                            fma_(hh, k1.dqx, e.qx), fma_(hh, k1.dqy, e.qy), fma_(hh, k1.dqz, e.qz), fma_(hh, k1.dwx, e.wx),
+                            fma_(hh, k1.dwy, e.wy), fma_(hh, k1.dwz, e.wz), Fm, Mx, My, Mz);
+    const Deriv<T> k3 = rhs(P, fma_(hh, k2.ax, e.vx), fma_(hh, k2.ay, e.vy), fma_(hh, k2.az, e.vz), fma_(hh, k2.dqw, e.qw),
+                            fma_(hh, k2.dqx, e.qx), fma_(hh, k2.dqy, e.qy), fma_(hh, k2.dqz, e.qz), fma_(hh, k2.dwx, e.wx),
+                            fma_(hh, k2.dwy, e.wy), fma_(hh, k2.dwz, e.wz), Fm, Mx, My, Mz);
+    const Deriv<T> k4 = rhs(P, fma_(h, k3.ax, e.vx), fma_(h, k3.ay, e.vy), fma_(h, k3.az, e.vz), fma_(h, k3.dqw, e.qw),
+                            fma_(h, k3.dqx, e.qx), fma_(h, k3.dqy, e.qy), fma_(h, k3.dqz, e.qz), fma_(h, k3.dwx, e.wx),
+                            fma_(h, k3.dwy, e.wy), fma_(h, k3.dwz, e.wz), Fm, Mx, My, Mz);
+    // y += h/6 (k1 + 2 k2 + 2 k3 + k4)
+#define AMENV_RK4(x, f) e.x = fma_(h6, fma_(T(2), k2.f + k3.f, k1.f + k4.f), e.x)
     AMENV_RK4(px, vx); AMENV_RK4(py, vy); AMENV_RK4(pz, vz);
     AMENV_RK4(vx, ax); AMENV_RK4(vy, ay); AMENV_RK4(vz, az);
     AMENV_RK4(qw, dqw); AMENV_RK4(qx, dqx); AMENV_RK4(qy, dqy); AMENV_RK4(qz, dqz);
     AMENV_RK4(wx, dwx); AMENV_RK4(wy, dwy); AMENV_RK4(wz, dwz);
 #undef AMENV_RK4
   }
-  const T rn = rsqrt_(e.qw * e.qw + e.qx * e.qx + e.qy * e.qy + e.qz * e.qz);   // :114
+  const T rn = rsqrt_(fma_(e.qw, e.qw, fma_(e.qx, e.qx, fma_(e.qy, e.qy, e.qz * e.qz))));   // :114
   e.qw *= rn; e.qx *= rn; e.qy *= rn; e.qz *= rn;
 }
 
@@ -164,17 +172,19 @@ __device__ __forceinline__ void observe(const Params<T>& P, const Env<T>& e, flo
   const int idx = e.flags & 255;
   T cx, cy, cz;
   current_waypoint(P, e, idx, cx, cy, cz);
-  o[0] = float(e.px / T(10)); o[1] = float(e.py / T(10)); o[2] = float(e.pz / T(10));
-  o[3] = float(e.vx / T(5)); o[4] = float(e.vy / T(5)); o[5] = float(e.vz / T(5));
+  // scalings as multiplications by the rounded reciprocal (<= 1 ulp from the reference's divisions)
+  const T c10 = T(0.1), c5 = T(0.2), c2 = T(0.5);
+  o[0] = float(e.px * c10); o[1] = float(e.py * c10); o[2] = float(e.pz * c10);
+  o[3] = float(e.vx * c5); o[4] = float(e.vy * c5); o[5] = float(e.vz * c5);
   o[6] = float(e.qw); o[7] = float(e.qx); o[8] = float(e.qy); o[9] = float(e.qz);
-  o[10] = float(e.wx / T(5)); o[11] = float(e.wy / T(5)); o[12] = float(e.wz / T(5));
-  o[13] = float((cx - e.px) / T(2)); o[14] = float((cy - e.py) / T(2)); o[15] = float((cz - e.pz) / T(2));
+  o[10] = float(e.wx * c5); o[11] = float(e.wy * c5); o[12] = float(e.wz * c5);
+  o[13] = float((cx - e.px) * c2); o[14] = float((cy - e.py) * c2); o[15] = float((cz - e.pz) * c2);
   T nx = T(0), ny = T(0), nz = T(0);
 #pragma unroll
   for (int k = 1; k < AMENV_MAX_WAYPOINTS; k++)
     if (k < P.K && idx == k - 1) { nx = e.wp[k][0] - cx; ny = e.wp[k][1] - cy; nz = e.wp[k][2] - cz; }
-  o[16] = float(nx / T(2)); o[17] = float(ny / T(2)); o[18] = float(nz / T(2));
-  o[19] = float(e.final_yaw / T(3.14159265358979323846));
+  o[16] = float(nx * c2); o[17] = float(ny * c2); o[18] = float(nz * c2);
+  o[19] = float(e.final_yaw * T(0.31830988618379067154));
 }
 
 // One WaypointQuadEnv.step (rl_env_scaledObs.py:123-196) after the dynamics update.
@@ -197,10 +207,10 @@ __device__ __forceinline__ uint32_t task_step(const Params<T>& P, Env<T>& e, T& 
   current_waypoint(P, e, idx, cx, cy, cz);
   // ---- _calculate_reward (:198-231)
   const T dx = e.px - cx, dy = e.py - cy, dz = e.pz - cz;
-  const T dist = sqrt_(dx * dx + dy * dy + dz * dz);                    // :204
+  const T dist = sqrt_(dot3_(dx, dy, dz, dx, dy, dz));                    // :204
   T r_dist = T(-10) * dist;                                             // :207
-  const T v2 = e.vx * e.vx + e.vy * e.vy + e.vz * e.vz;
-  const T w2 = e.wx * e.wx + e.wy * e.wy + e.wz * e.wz;
+  const T v2 = dot3_(e.vx, e.vy, e.vz, e.vx, e.vy, e.vz);
+  const T w2 = dot3_(e.wx, e.wy, e.wz, e.wx, e.wy, e.wz);
   const T vn = sqrt_(v2), wn = sqrt_(w2);
   T r_speed = T(-0.1) * v2;                                             // :208
   if (wn > T(0.1)) r_speed -= T(0.01) * w2;                             // :209-210
@@ -223,11 +233,11 @@ __device__ __forceinline__ uint32_t task_step(const Params<T>& P, Env<T>& e, T& 
     if (idx >= P.K) {                                                   // :153 (else: next waypoint, fall through)
       idx = P.K;                                                        // waypoint_index == len(list)
       // roll, pitch, yaw (utils2/utils.py:4-9 closed form); only the hold-phase bonuses use them
-      const T roll = atan2_(T(2) * (e.qw * e.qx + e.qy * e.qz), T(1) - T(2) * (e.qx * e.qx + e.qy * e.qy));
-      T sp = T(2) * (e.qw * e.qy - e.qz * e.qx);
+      const T roll = atan2_(T(2) * fma_(e.qw, e.qx, e.qy * e.qz), fma_(T(-2), fma_(e.qx, e.qx, e.qy * e.qy), T(1)));
+      T sp = T(2) * fma_(e.qw, e.qy, -(e.qz * e.qx));
       sp = sp > T(1) ? T(1) : (sp < T(-1) ? T(-1) : sp);
       const T pitch = asin_(sp);
-      const T yaw = atan2_(T(2) * (e.qw * e.qz + e.qx * e.qy), T(1) - T(2) * (e.qy * e.qy + e.qz * e.qz));
+      const T yaw = atan2_(T(2) * fma_(e.qw, e.qz, e.qx * e.qy), fma_(T(-2), fma_(e.qy, e.qy, e.qz * e.qz), T(1)));
       const T two_pi = T(6.28318530717958647692);
       const T dyaw = abs_(yaw - e.final_yaw);
       bits |= AMENV_INFO_SUCCESS;
@@ -255,7 +265,7 @@ __device__ __forceinline__ uint32_t task_step(const Params<T>& P, Env<T>& e, T& 
       reward -= T(100);
       if (e.vz < T(0)) reward += e.vz * T(100);
       bits |= AMENV_INFO_TERMINATED | AMENV_INFO_CRASHED;
-    } else if (sqrt_(e.px * e.px + e.py * e.py + e.pz * e.pz) > T(10)) { // :193-195
+    } else if (sqrt_(dot3_(e.px, e.py, e.pz, e.px, e.py, e.pz)) > T(10)) { // :193-195
       reward -= T(100);
       bits |= AMENV_INFO_TERMINATED | AMENV_INFO_OOB;
     }
@@ -308,11 +318,11 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, Env<T>& e, int64_t
       wy = fmaf(0.8f, P.traj_sin[k - 1], sy);
       wz = fmaxf(fmaf(float(k), 0.4f, sz), 0.2f);
     } else {                                                            // linear / curved, :12-57
-      const float t = __fdiv_rn(float(k), float(P.K));
-      wx = fmaf(t, __fsub_rn(ex, sx), sx); wy = fmaf(t, __fsub_rn(ey, sy), sy); wz = fmaf(t, __fsub_rn(ez, sz), sz);
+      const float t = float(k) / float(P.K);
+      wx = fmaf(t, ex - sx, sx); wy = fmaf(t, ey - sy, sy); wz = fmaf(t, ez - sz, sz);
       if (kind == 1) {
         const float s = P.traj_sin[k - 1];
-        if (axis == 0) wz = __fadd_rn(wz, s); else if (axis == 1) wy = __fadd_rn(wy, s); else wx = __fadd_rn(wx, s);
+        if (axis == 0) wz = wz + s; else if (axis == 1) wy = wy + s; else wx = wx + s;
         wz = fmaxf(wz, 0.2f);
       }
     }

@@ -112,6 +112,17 @@ class GpuWaypointEnv:
                     "amenv_step")
         return self.obs, self.reward, self.done, self.info_bits
 
+    def step_timed(self, actions):
+        """step() that also returns the device-side duration (us) of that one kernel launch (synchronises)."""
+        a = self._actions(actions)
+        us = C.c_float()
+        self._check(self.lib.amenv_step_timed(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                              C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                              C.c_void_p(self.info_bits.data_ptr()), C.c_void_p(self.terminal_obs.data_ptr()),
+                                              C.c_void_p(self.ep_return.data_ptr()), C.c_void_p(self.ep_len.data_ptr()), self._stream(),
+                                              C.byref(us)), "amenv_step_timed")
+        return us.value
+
     def rollout(self, actions, want_obs=True, want_flags=True):
         """T open-loop steps in one launch; actions [T,N,4].  Returns dict of [T,N,...] tensors."""
         T = int(actions.shape[0])
