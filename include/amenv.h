@@ -112,7 +112,7 @@ typedef struct amenv_config {
   int32_t num_envs;     /* N on THIS device */
   int32_t dtype;        /* AMENV_F32 | AMENV_F64 */
   uint32_t flags;       /* AMENV_FLAG_* */
-  int32_t block_size;   /* 0 = auto; else threads per workgroup (multiple of 64) */
+  int32_t block_size;   /* 0 = auto; else threads per workgroup: 64, 128, 192 or 256 */
   uint64_t seed;        /* reset RNG seed (Philox4x32-10 key) */
   int64_t env_id_offset; /* global id of local env 0: RNG is keyed by GLOBAL env id, so
                             results do not depend on how envs are sharded over GPUs */

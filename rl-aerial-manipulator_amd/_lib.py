@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libamenv.so")
+# AMENV_LIB lets tools/ab_kernel.py load an alternative build of the SAME library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("AMENV_LIB") or os.path.join(HERE, "libamenv.so")
 
 MAX_ROTORS, MAX_WAYPOINTS, MAX_JOINTS = 8, 4, 3
 ABI_VERSION = 1

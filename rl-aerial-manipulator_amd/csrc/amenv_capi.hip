@@ -19,10 +19,11 @@ struct amenv {
   amenv_config cfg;
   int device = -1;
   int obs_dim = kObsDim, act_dim = kActDim, nf = 0;
-  void* fstate = nullptr;
-  int32_t* istate = nullptr;
+  void* blob = nullptr;            // tiled episode state (amenv_kernels.hpp "Data layout")
   unsigned long long* stats = nullptr;
-  size_t fbytes = 0, ibytes = 0;
+  size_t blob_bytes = 0, fbytes = 0, ibytes = 0;
+  uint32_t tile_bytes = 0;
+  int n_tiles = 0;
   int block = 64;
   uint64_t steps = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // amenv_step_timed only
@@ -142,29 +143,36 @@ bool vehicle_hexa(amenv_vehicle* v) {
   return true;
 }
 
-template <typename T>
-Params<T> make_params(const amenv& e) {
+template <typename T, int NR>
+HotParams<T, NR> make_hot(const amenv& e) {
   const amenv_config& c = e.cfg;
   const amenv_vehicle& v = c.vehicle;
-  Params<T> P;
+  HotParams<T, NR> P;
   std::memset(&P, 0, sizeof(P));
-  P.mass = T(v.mass); P.inv_mass = T(1.0 / v.mass); P.g = T(v.g);
-  for (int i = 0; i < 9; i++) { P.I[i] = T(v.inertia[i]); P.J[i] = T(v.inv_inertia[i]); }
   for (int r = 0; r < v.n_rotors; r++) {
-    for (int j = 0; j < 4; j++) { P.alloc[r][j] = T(v.alloc[r * 4 + j]); P.mix[j][r] = T(v.mix[j * v.n_rotors + r]); }
+    for (int j = 0; j < 4; j++) P.alloc[r][j] = T(v.alloc[r * 4 + j]);
+    for (int j = 0; j < 3; j++) P.mixm[j][r] = T(v.mix[(1 + j) * v.n_rotors + r]);
     P.tmin[r] = T(v.t_min[r]); P.tmax[r] = T(v.t_max[r]);
   }
+  const double* I = v.inertia; const double* J = v.inv_inertia;
+  P.Ixx = T(I[0]); P.Ixy = T(I[1]); P.Ixz = T(I[2]); P.Iyy = T(I[4]); P.Iyz = T(I[5]); P.Izz = T(I[8]);
+  P.Jxx = T(J[0]); P.Jxy = T(J[1]); P.Jxz = T(J[2]); P.Jyy = T(J[4]); P.Jyz = T(J[5]); P.Jzz = T(J[8]);
   const int ns = c.task.rk4_substeps > 0 ? c.task.rk4_substeps : 1;
-  P.h = T(c.task.dt / ns);
+  P.inv_mass = T(1.0 / v.mass); P.g = T(v.g); P.h = T(c.task.dt / ns);
   P.mass_f = float(v.mass); P.g_f = float(v.g); P.mscale_f = float(v.moment_scale);
-  for (int k = 0; k < AMENV_MAX_WAYPOINTS; k++) { P.traj_sin[k] = float(c.task.traj_sin[k]); P.traj_cos[k] = float(c.task.traj_cos[k]); }
-  P.n_rotors = v.n_rotors; P.substeps = ns; P.K = c.task.num_waypoints;
+  P.n_rotors = v.n_rotors; P.substeps = ns;
   P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit;
-  P.flags = c.flags;
-  P.seed_lo = uint32_t(c.seed); P.seed_hi = uint32_t(c.seed >> 32);
-  P.gid0 = c.env_id_offset;
-  P.n = c.num_envs; P.nf = e.nf;
+  P.flags = c.flags; P.n = c.num_envs; P.K = c.task.num_waypoints; P.tile_bytes = e.tile_bytes;
   return P;
+}
+
+ColdParams make_cold(const amenv& e) {
+  const amenv_config& c = e.cfg;
+  ColdParams C;
+  for (int k = 0; k < AMENV_MAX_WAYPOINTS; k++) { C.traj_sin[k] = float(c.task.traj_sin[k]); C.traj_cos[k] = float(c.task.traj_cos[k]); }
+  C.seed_lo = uint32_t(c.seed); C.seed_hi = uint32_t(c.seed >> 32);
+  C.gid0 = c.env_id_offset;
+  return C;
 }
 
 int n_float_fields(const amenv_config* c) { return AMENV_F_WP0 + 3 * c->task.num_waypoints + 3 * c->vehicle.n_joints; }
@@ -181,51 +189,61 @@ const char* validate(const amenv_config* c) {
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
   if (c->task.max_episode_steps < 1 || c->task.counter_limit < 0) return "bad episode limits";
   if (!(c->task.dt > 0.0) || !(c->vehicle.mass > 0.0)) return "dt and mass must be positive";
-  if (c->block_size != 0 && c->block_size != 64 && c->block_size != 256) return "block_size must be 0, 64 or 256";
+  for (int r = 0; r < c->vehicle.n_rotors; r++)
+    if (std::fabs(c->vehicle.mix[r] - 1.0) > 1e-12) return "mix row 0 must be all ones: total thrust is the plain sum of rotor thrusts (quadcopter.py:111)";
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < i; j++)
+      if (std::fabs(c->vehicle.inertia[i * 3 + j] - c->vehicle.inertia[j * 3 + i]) > 1e-15 ||
+          std::fabs(c->vehicle.inv_inertia[i * 3 + j] - c->vehicle.inv_inertia[j * 3 + i]) > 1e-6 * std::fabs(c->vehicle.inv_inertia[i * 3 + i]))
+        return "inertia and inv_inertia must be symmetric";
+  if (c->block_size != 0 && (c->block_size < 64 || c->block_size > 256 || c->block_size % 64)) return "block_size must be 0, 64, 128, 192 or 256";
   return nullptr;
 }
 
-template <typename T, int NROT>
-hipError_t launch_step(const amenv& e, const StepIO& io, hipStream_t s, bool timed) {
-  const Params<T> P = make_params<T>(e);
-  const int n = e.cfg.num_envs;
-  if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
-    if (e.block == 64) {
-      hipExtLaunchKernelGGL((step_kernel<T, NROT, 64>), dim3((n + 63) / 64), dim3(64), 0, s, e.ev_start, e.ev_stop, 0, P, (T*)e.fstate, e.istate, io);
-    } else {
-      hipExtLaunchKernelGGL((step_kernel<T, NROT, 256>), dim3((n + 255) / 256), dim3(256), 0, s, e.ev_start, e.ev_stop, 0, P, (T*)e.fstate, e.istate, io);
-    }
-  } else if (e.block == 64) {
-    hipLaunchKernelGGL((step_kernel<T, NROT, 64>), dim3((n + 63) / 64), dim3(64), 0, s, P, (T*)e.fstate, e.istate, io);
+template <typename T, int NROT, int KW>
+hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed) {
+  const HotParams<T, NROT> P = make_hot<T, NROT>(e);
+  const ColdParams C = make_cold(e);
+  const int bs = e.block, n_pad = e.n_tiles * 64;
+  const dim3 grid((n_pad + bs - 1) / bs), block(bs);
+  const size_t lds = size_t(bs) * kObsDim * sizeof(float);
+  if (T_steps > 0) {
+    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW>), grid, block, lds, s, P, C, e.blob, io, T_steps);
+  } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
+    hipExtLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, P, C, e.blob, io);
   } else {
-    hipLaunchKernelGGL((step_kernel<T, NROT, 256>), dim3((n + 255) / 256), dim3(256), 0, s, P, (T*)e.fstate, e.istate, io);
+    hipLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, P, C, e.blob, io);
   }
   return hipGetLastError();
 }
 
 template <typename T, int NROT>
-hipError_t launch_rollout(const amenv& e, const StepIO& io, int T_steps, hipStream_t s) {
-  const Params<T> P = make_params<T>(e);
-  const int n = e.cfg.num_envs;
-  if (e.block == 64) {
-    hipLaunchKernelGGL((rollout_kernel<T, NROT, 64>), dim3((n + 63) / 64), dim3(64), 0, s, P, (T*)e.fstate, e.istate, io, T_steps);
-  } else {
-    hipLaunchKernelGGL((rollout_kernel<T, NROT, 256>), dim3((n + 255) / 256), dim3(256), 0, s, P, (T*)e.fstate, e.istate, io, T_steps);
-  }
-  return hipGetLastError();
+hipError_t dispatch_k(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed) {
+  if (e.cfg.task.num_waypoints == 1) return launch_step<T, NROT, 1>(e, io, T_steps, s, timed);
+  return launch_step<T, NROT, AMENV_MAX_WAYPOINTS>(e, io, T_steps, s, timed);
 }
 
 template <typename T>
 hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed = false) {
   const int nr = e.cfg.vehicle.n_rotors;
-  if (T_steps == 0) {
-    if (nr == 4) return launch_step<T, 4>(e, io, s, timed);
-    if (nr == 6) return launch_step<T, 6>(e, io, s, timed);
-    return launch_step<T, 0>(e, io, s, timed);
-  }
-  if (nr == 4) return launch_rollout<T, 4>(e, io, T_steps, s);
-  if (nr == 6) return launch_rollout<T, 6>(e, io, T_steps, s);
-  return launch_rollout<T, 0>(e, io, T_steps, s);
+  if (nr == 4) return dispatch_k<T, 4>(e, io, T_steps, s, timed);
+  if (nr == 6) return dispatch_k<T, 6>(e, io, T_steps, s, timed);
+  return dispatch_k<T, AMENV_MAX_ROTORS>(e, io, T_steps, s, timed);
+}
+
+template <typename T>
+hipError_t launch_reset(const amenv& e, const uint8_t* mask, float* obs, int pad_only, hipStream_t s) {
+  const int bs = 256, n_pad = e.n_tiles * 64;
+  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, e.cfg.task.num_waypoints, e.tile_bytes,
+                     make_cold(e), e.blob, mask, obs, pad_only);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_transpose(const amenv& e, void* f, int32_t* i, int to_api, hipStream_t s) {
+  const int bs = 256, n = e.cfg.num_envs;
+  hipLaunchKernelGGL((transpose_state_kernel<T>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, e.nf, e.tile_bytes, e.blob, (T*)f, i, to_api);
+  return hipGetLastError();
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -296,22 +314,29 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   const size_t n = size_t(cfg->num_envs), ts = cfg->dtype == AMENV_F64 ? 8 : 4;
   e->fbytes = size_t(e->nf) * n * ts;
   e->ibytes = size_t(AMENV_I_NFIELDS) * n * sizeof(int32_t);
+  e->n_tiles = int((n + 63) / 64);
+  e->tile_bytes = tile_bytes_for(e->nf, int(ts));
+  e->blob_bytes = size_t(e->n_tiles) * e->tile_bytes;
   // latency regime (few waves per CU): one wave per workgroup spreads the waves over more CUs;
   // throughput regime: 256-thread workgroups
   e->block = cfg->block_size ? cfg->block_size : (cfg->num_envs <= 65536 ? 64 : 256);
   DeviceGuard g(device);
   hipError_t s;
-  if ((s = hipMalloc(&e->fstate, e->fbytes)) != hipSuccess || (s = hipMalloc((void**)&e->istate, e->ibytes)) != hipSuccess ||
+  if ((s = hipMalloc(&e->blob, e->blob_bytes)) != hipSuccess ||
       (s = hipMalloc((void**)&e->stats, sizeof(unsigned long long) * S_COUNT)) != hipSuccess ||
-      (s = hipMemset(e->fstate, 0, e->fbytes)) != hipSuccess || (s = hipMemset(e->istate, 0, e->ibytes)) != hipSuccess ||
-      (s = hipMemset(e->stats, 0, sizeof(unsigned long long) * S_COUNT)) != hipSuccess) {
+      (s = hipMemset(e->blob, 0, e->blob_bytes)) != hipSuccess ||
+      (s = hipMemset(e->stats, 0, sizeof(unsigned long long) * S_COUNT)) != hipSuccess ||
+      // give the padding lanes of the last tile a valid state (real envs stay untouched: episode 0)
+      (s = (cfg->dtype == AMENV_F64 ? launch_reset<double>(*e, nullptr, nullptr, 1, nullptr) : launch_reset<float>(*e, nullptr, nullptr, 1, nullptr))) != hipSuccess ||
+      (s = hipDeviceSynchronize()) != hipSuccess) {
     std::string msg = std::string("amenv_create: device allocation failed: ") + hipGetErrorString(s);
     amenv_destroy(e);
     return fail(nullptr, AMENV_ERR_ALLOC, msg);
   }
   char buf[160];
-  std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,BS=%d>", cfg->dtype == AMENV_F64 ? "double" : "float",
-                (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : 0, e->block);
+  std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
+                (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
+                cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS, e->block);
   e->kname = buf;
   *out = e;
   return AMENV_OK;
@@ -321,8 +346,7 @@ int amenv_destroy(amenv* e) {
   if (!e) return AMENV_OK;
   {
     DeviceGuard g(e->device);
-    if (e->fstate) (void)hipFree(e->fstate);
-    if (e->istate) (void)hipFree(e->istate);
+    if (e->blob) (void)hipFree(e->blob);
     if (e->stats) (void)hipFree(e->stats);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
@@ -338,13 +362,7 @@ int amenv_reset(amenv* e, const uint8_t* mask, float* obs_out, void* stream) {
   if (!e) return AMENV_ERR_INVALID;
   DeviceGuard g(e->device);
   hipStream_t s = (hipStream_t)stream;
-  const int n = e->cfg.num_envs, bs = 256;
-  if (e->cfg.dtype == AMENV_F64) {
-    hipLaunchKernelGGL((reset_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<double>(*e), (double*)e->fstate, e->istate, mask, obs_out);
-  } else {
-    hipLaunchKernelGGL((reset_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<float>(*e), (float*)e->fstate, e->istate, mask, obs_out);
-  }
-  AMENV_HIP(e, hipGetLastError());
+  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_reset<double>(*e, mask, obs_out, 0, s) : launch_reset<float>(*e, mask, obs_out, 0, s));
   return AMENV_OK;
 }
 
@@ -352,11 +370,11 @@ int amenv_observe(amenv* e, float* obs_out, void* stream) {
   if (!e || !obs_out) return fail(e, AMENV_ERR_INVALID, "amenv_observe: NULL argument");
   DeviceGuard g(e->device);
   hipStream_t s = (hipStream_t)stream;
-  const int n = e->cfg.num_envs, bs = 256;
+  const int n = e->cfg.num_envs, bs = 256, K = e->cfg.task.num_waypoints;
   if (e->cfg.dtype == AMENV_F64) {
-    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<double>(*e), (const double*)e->fstate, e->istate, obs_out);
+    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->tile_bytes, (const void*)e->blob, obs_out);
   } else {
-    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, make_params<float>(*e), (const float*)e->fstate, e->istate, obs_out);
+    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->tile_bytes, (const void*)e->blob, obs_out);
   }
   AMENV_HIP(e, hipGetLastError());
   return AMENV_OK;
@@ -371,7 +389,7 @@ int amenv_step(amenv* e, const float* actions, float* obs, void* reward, uint8_t
   DeviceGuard g(e->device);
   StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, terminal_obs, ep_return, ep_len, e->stats};
   hipStream_t s = (hipStream_t)stream;
-  hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, 0, s) : dispatch_step<float>(*e, io, 0, s);
+  hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, 0, s, false) : dispatch_step<float>(*e, io, 0, s, false);
   AMENV_HIP(e, st);
   e->steps += uint64_t(e->cfg.num_envs);
   return AMENV_OK;
@@ -414,16 +432,17 @@ int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, v
 int amenv_get_state(amenv* e, void* fstate, int32_t* istate, void* stream) {
   if (!e) return AMENV_ERR_INVALID;
   DeviceGuard g(e->device);
-  if (fstate) AMENV_HIP(e, hipMemcpyAsync(fstate, e->fstate, e->fbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  if (istate) AMENV_HIP(e, hipMemcpyAsync(istate, e->istate, e->ibytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  hipStream_t s = (hipStream_t)stream;
+  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_transpose<double>(*e, fstate, istate, 1, s) : launch_transpose<float>(*e, fstate, istate, 1, s));
   return AMENV_OK;
 }
 
 int amenv_set_state(amenv* e, const void* fstate, const int32_t* istate, void* stream) {
   if (!e) return AMENV_ERR_INVALID;
   DeviceGuard g(e->device);
-  if (fstate) AMENV_HIP(e, hipMemcpyAsync(e->fstate, fstate, e->fbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  if (istate) AMENV_HIP(e, hipMemcpyAsync(e->istate, istate, e->ibytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  hipStream_t s = (hipStream_t)stream;
+  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_transpose<double>(*e, const_cast<void*>(fstate), const_cast<int32_t*>(istate), 0, s)
+                                          : launch_transpose<float>(*e, const_cast<void*>(fstate), const_cast<int32_t*>(istate), 0, s));
   return AMENV_OK;
 }
 

@@ -27,29 +27,38 @@ namespace amenv_dev {
 constexpr int kObsDim = 20;  // v2 observation
 constexpr int kActDim = 4;
 
-// ---- kernel-argument constants (uniform: live in SGPRs / scalar loads) -------------------
-template <typename T>
-struct Params {
-  T mass, inv_mass, g;
-  T I[9], J[9];                       // inertia, inverse inertia (row-major)
-  T alloc[AMENV_MAX_ROTORS][4];       // rotor thrusts = alloc . [F,Mx,My,Mz]
-  T mix[4][AMENV_MAX_ROTORS];         // [F,Mx,My,Mz] = mix . thrusts
-  T tmin[AMENV_MAX_ROTORS], tmax[AMENV_MAX_ROTORS];
-  T h;                                // dt / substeps
-  float mass_f, g_f, mscale_f;        // action scaling is fp32 in the reference (NumPy >= 2 promotion)
-  float traj_sin[AMENV_MAX_WAYPOINTS], traj_cos[AMENV_MAX_WAYPOINTS];
-  int32_t n_rotors, substeps, K, max_steps, counter_limit;
+// ---- kernel-argument constants (uniform: they live in SGPRs) ----------------------------------
+// Hot parameters are kept COMPACT (rotor-count-sized mixer, symmetric inertia) so that one batch of
+// scalar loads at kernel entry brings all of them into the ~100 available SGPRs: with 64 lone
+// wavefronts per launch every extra dependent scalar-load phase is ~0.3 us of pure latency.
+template <typename T, int NR>
+struct HotParams {
+  T alloc[NR][4];   // rotor thrusts = alloc . [F,Mx,My,Mz]            (quadcopter.py:109)
+  T mixm[3][NR];    // [Mx,My,Mz] = mixm . thrusts; F = sum(thrusts)    (quadcopter.py:111-112)
+  T tmin[NR], tmax[NR];
+  T Ixx, Ixy, Ixz, Iyy, Iyz, Izz;   // inertia (symmetric)
+  T Jxx, Jxy, Jxz, Jyy, Jyz, Jzz;   // inverse inertia (symmetric)
+  T inv_mass, g, h;                 // h = dt / substeps
+  float mass_f, g_f, mscale_f;      // action scaling is fp32 in the reference (NumPy >= 2 promotion)
+  int32_t n_rotors;                 // used only by the generic (NR = AMENV_MAX_ROTORS) instantiation
+  int32_t substeps, max_steps, counter_limit;
   uint32_t flags;
+  int32_t n;                        // envs on this device
+  int32_t K;                        // waypoints per episode (<= KW of the instantiation)
+  uint32_t tile_bytes;              // bytes of one 64-env state tile
+};
+
+// Parameters only the reset path needs (cold: loaded when a lane actually resets).
+struct ColdParams {
+  float traj_sin[AMENV_MAX_WAYPOINTS], traj_cos[AMENV_MAX_WAYPOINTS];
   uint32_t seed_lo, seed_hi;
-  int64_t gid0;                       // global id of local env 0
-  int32_t n;                          // envs on this device
-  int32_t nf;                         // float fields
+  int64_t gid0;                     // global id of local env 0
 };
 
 // ---- math helpers: one definition per arithmetic type ------------------------------------
 __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp, 1 instr
 __device__ __forceinline__ double rcp_(double x) { return 1.0 / x; }
-__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }                  // correctly rounded
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp, 1 instr
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float rsqrt_(float x) {                                     // v_rsq + one Newton step
   float y = __builtin_amdgcn_rsqf(x);
@@ -66,10 +75,10 @@ __device__ __forceinline__ bool finite_(float a) { return __builtin_isfinite(a);
 __device__ __forceinline__ bool finite_(double a) { return __builtin_isfinite(a); }
 
 // ---- per-env registers ------------------------------------------------------------------------
-template <typename T>
+template <typename T, int KW>
 struct Env {
   T px, py, pz, vx, vy, vz, qw, qx, qy, qz, wx, wy, wz;
-  T wp[AMENV_MAX_WAYPOINTS][3];
+  T wp[KW][3];
   T final_yaw, last_distance, ep_return;
   int32_t step, counter, flags, episode;
 };
@@ -85,8 +94,8 @@ __device__ __forceinline__ double fma_(double a, double b, double c) { return __
 template <typename T> __device__ __forceinline__ T dot3_(T a0, T a1, T a2, T b0, T b1, T b2) { return fma_(a0, b0, fma_(a1, b1, a2 * b2)); }
 
 // ODE right-hand side (quadcopter.py:66-103).  F, M: post-mixer wrench, constant over the step.
-template <typename T>
-__device__ __forceinline__ Deriv<T> rhs(const Params<T>& P, T vx, T vy, T vz, T qw, T qx, T qy, T qz, T p, T q, T r, T Fm,
+template <typename T, typename PT>
+__device__ __forceinline__ Deriv<T> rhs(const PT& P, T vx, T vy, T vz, T qw, T qx, T qy, T qz, T p, T q, T r, T Fm,
                                         T Mx, T My, T Mz) {
   Deriv<T> d;
   // third column of wRb for the NORMALISED quaternion: quadratic in q/|q| => divide by |q|^2 once
@@ -104,46 +113,45 @@ __device__ __forceinline__ Deriv<T> rhs(const Params<T>& P, T vx, T vy, T vz, T 
   d.dqy = fma_(T(-0.5), fma_(q, qw, fma_(r, qx, -(p * qz))), k * qy);
   d.dqz = fma_(T(-0.5), fma_(r, qw, fma_(p, qy, -(q * qx))), k * qz);
   // pqrdot = invI (M - w x (I w))                               :86-87
-  const T i0 = dot3_(P.I[0], P.I[1], P.I[2], p, q, r);
-  const T i1 = dot3_(P.I[3], P.I[4], P.I[5], p, q, r);
-  const T i2 = dot3_(P.I[6], P.I[7], P.I[8], p, q, r);
+  const T i0 = dot3_(P.Ixx, P.Ixy, P.Ixz, p, q, r);
+  const T i1 = dot3_(P.Ixy, P.Iyy, P.Iyz, p, q, r);
+  const T i2 = dot3_(P.Ixz, P.Iyz, P.Izz, p, q, r);
   const T t0 = Mx - fma_(q, i2, -(r * i1));
   const T t1 = My - fma_(r, i0, -(p * i2));
   const T t2 = Mz - fma_(p, i1, -(q * i0));
-  d.dwx = dot3_(P.J[0], P.J[1], P.J[2], t0, t1, t2);
-  d.dwy = dot3_(P.J[3], P.J[4], P.J[5], t0, t1, t2);
-  d.dwz = dot3_(P.J[6], P.J[7], P.J[8], t0, t1, t2);
+  d.dwx = dot3_(P.Jxx, P.Jxy, P.Jxz, t0, t1, t2);
+  d.dwy = dot3_(P.Jxy, P.Jyy, P.Jyz, t0, t1, t2);
+  d.dwz = dot3_(P.Jxz, P.Jyz, P.Jzz, t0, t1, t2);
   return d;
 }
 
 // Quadcopter.update (quadcopter.py:105-114) with RK4 in place of odeint.
-template <typename T, int NROT>
-__device__ __forceinline__ void dynamics(const Params<T>& P, Env<T>& e, float a0, float a1, float a2, float a3) {
+template <typename T, int NROT, int KW>
+__device__ __forceinline__ void dynamics(const HotParams<T, NROT>& P, Env<T, KW>& e, float a0, float a1, float a2, float a3) {
   // action scaling in fp32, left to right (rl_env_scaledObs.py:125-126)
   const float Ff = (a0 * P.mass_f) * P.g_f;
   const T u0 = T(Ff), u1 = T(a1 * P.mscale_f), u2 = T(a2 * P.mscale_f), u3 = T(a3 * P.mscale_f);
   // mixer -> per-rotor clamp -> re-mix (:109-112)
-  constexpr int NR = NROT > 0 ? NROT : AMENV_MAX_ROTORS;
   T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
 #pragma unroll
-  for (int r = 0; r < NR; r++) {
-    if (NROT == 0 && r >= P.n_rotors) break;
+  for (int r = 0; r < NROT; r++) {
+    if (NROT == AMENV_MAX_ROTORS && r >= P.n_rotors) break;  // generic instantiation: runtime rotor count
     T t = fma_(P.alloc[r][0], u0, fma_(P.alloc[r][1], u1, fma_(P.alloc[r][2], u2, P.alloc[r][3] * u3)));
     t = t < P.tmax[r] ? t : P.tmax[r];
     t = t > P.tmin[r] ? t : P.tmin[r];
-    F = fma_(P.mix[0][r], t, F); Mx = fma_(P.mix[1][r], t, Mx); My = fma_(P.mix[2][r], t, My); Mz = fma_(P.mix[3][r], t, Mz);
+    F = F + t; Mx = fma_(P.mixm[0][r], t, Mx); My = fma_(P.mixm[1][r], t, My); Mz = fma_(P.mixm[2][r], t, Mz);
   }
   const T Fm = F * P.inv_mass;
   const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
   for (int it = 0; it < P.substeps; it++) {
-    const Deriv<T> k1 = rhs(P, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz, Fm, Mx, My, Mz);
-    const Deriv<T> k2 = rhs(P, fma_(hh, k1.ax, e.vx), fma_(hh, k1.ay, e.vy), fma_(hh, k1.az, e.vz), fma_(hh, k1.dqw, e.qw),
+    const Deriv<T> k1 = rhs<T>(P, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz, Fm, Mx, My, Mz);
+    const Deriv<T> k2 = rhs<T>(P, fma_(hh, k1.ax, e.vx), fma_(hh, k1.ay, e.vy), fma_(hh, k1.az, e.vz), fma_(hh, k1.dqw, e.qw),
                             fma_(hh, k1.dqx, e.qx), fma_(hh, k1.dqy, e.qy), fma_(hh, k1.dqz, e.qz), fma_(hh, k1.dwx, e.wx),
                             fma_(hh, k1.dwy, e.wy), fma_(hh, k1.dwz, e.wz), Fm, Mx, My, Mz);
-    const Deriv<T> k3 = rhs(P, fma_(hh, k2.ax, e.vx), fma_(hh, k2.ay, e.vy), fma_(hh, k2.az, e.vz), fma_(hh, k2.dqw, e.qw),
+    const Deriv<T> k3 = rhs<T>(P, fma_(hh, k2.ax, e.vx), fma_(hh, k2.ay, e.vy), fma_(hh, k2.az, e.vz), fma_(hh, k2.dqw, e.qw),
                             fma_(hh, k2.dqx, e.qx), fma_(hh, k2.dqy, e.qy), fma_(hh, k2.dqz, e.qz), fma_(hh, k2.dwx, e.wx),
                             fma_(hh, k2.dwy, e.wy), fma_(hh, k2.dwz, e.wz), Fm, Mx, My, Mz);
-    const Deriv<T> k4 = rhs(P, fma_(h, k3.ax, e.vx), fma_(h, k3.ay, e.vy), fma_(h, k3.az, e.vz), fma_(h, k3.dqw, e.qw),
+    const Deriv<T> k4 = rhs<T>(P, fma_(h, k3.ax, e.vx), fma_(h, k3.ay, e.vy), fma_(h, k3.az, e.vz), fma_(h, k3.dqw, e.qw),
                             fma_(h, k3.dqx, e.qx), fma_(h, k3.dqy, e.qy), fma_(h, k3.dqz, e.qz), fma_(h, k3.dwx, e.wx),
                             fma_(h, k3.dwy, e.wy), fma_(h, k3.dwz, e.wz), Fm, Mx, My, Mz);
     // y += h/6 (k1 + 2 k2 + 2 k3 + k4)
@@ -158,20 +166,20 @@ __device__ __forceinline__ void dynamics(const Params<T>& P, Env<T>& e, float a0
   e.qw *= rn; e.qx *= rn; e.qy *= rn; e.qz *= rn;
 }
 
-template <typename T>
-__device__ __forceinline__ void current_waypoint(const Params<T>& P, const Env<T>& e, int idx, T& cx, T& cy, T& cz) {
+template <typename T, int KW>
+__device__ __forceinline__ void current_waypoint(int K, const Env<T, KW>& e, int idx, T& cx, T& cy, T& cz) {
   cx = e.wp[0][0]; cy = e.wp[0][1]; cz = e.wp[0][2];
 #pragma unroll
-  for (int k = 1; k < AMENV_MAX_WAYPOINTS; k++)
-    if (k < P.K && idx >= k) { cx = e.wp[k][0]; cy = e.wp[k][1]; cz = e.wp[k][2]; }
+  for (int k = 1; k < KW; k++)
+    if (k < K && idx >= k) { cx = e.wp[k][0]; cy = e.wp[k][1]; cz = e.wp[k][2]; }
 }
 
 // _get_observation (rl_env_scaledObs.py:98-121)
-template <typename T>
-__device__ __forceinline__ void observe(const Params<T>& P, const Env<T>& e, float* o) {
+template <typename T, int KW>
+__device__ __forceinline__ void observe(int K, const Env<T, KW>& e, float* o) {
   const int idx = e.flags & 255;
   T cx, cy, cz;
-  current_waypoint(P, e, idx, cx, cy, cz);
+  current_waypoint(K, e, idx, cx, cy, cz);
   // scalings as multiplications by the rounded reciprocal (<= 1 ulp from the reference's divisions)
   const T c10 = T(0.1), c5 = T(0.2), c2 = T(0.5);
   o[0] = float(e.px * c10); o[1] = float(e.py * c10); o[2] = float(e.pz * c10);
@@ -181,16 +189,17 @@ __device__ __forceinline__ void observe(const Params<T>& P, const Env<T>& e, flo
   o[13] = float((cx - e.px) * c2); o[14] = float((cy - e.py) * c2); o[15] = float((cz - e.pz) * c2);
   T nx = T(0), ny = T(0), nz = T(0);
 #pragma unroll
-  for (int k = 1; k < AMENV_MAX_WAYPOINTS; k++)
-    if (k < P.K && idx == k - 1) { nx = e.wp[k][0] - cx; ny = e.wp[k][1] - cy; nz = e.wp[k][2] - cz; }
+  for (int k = 1; k < KW; k++)
+    if (k < K && idx == k - 1) { nx = e.wp[k][0] - cx; ny = e.wp[k][1] - cy; nz = e.wp[k][2] - cz; }
   o[16] = float(nx * c2); o[17] = float(ny * c2); o[18] = float(nz * c2);
   o[19] = float(e.final_yaw * T(0.31830988618379067154));
 }
 
 // One WaypointQuadEnv.step (rl_env_scaledObs.py:123-196) after the dynamics update.
 // Returns info bits; reward in `reward`.  Mutates the episode registers.
-template <typename T>
-__device__ __forceinline__ uint32_t task_step(const Params<T>& P, Env<T>& e, T& reward) {
+template <typename T, int KW, typename PT>
+__device__ __forceinline__ uint32_t task_step(const PT& P, Env<T, KW>& e, T& reward) {
+  const int K = KW == 1 ? 1 : P.K;
   uint32_t bits = 0;
   int idx = e.flags & 255;
   bool fwr = (e.flags & AMENV_FLAGBIT_FWR) != 0;
@@ -204,7 +213,7 @@ __device__ __forceinline__ uint32_t task_step(const Params<T>& P, Env<T>& e, T& 
     if (!finite_(sum)) { reward = T(-100); return bits | AMENV_INFO_TERMINATED | AMENV_INFO_NONFINITE; }
   }
   T cx, cy, cz;
-  current_waypoint(P, e, idx, cx, cy, cz);
+  current_waypoint(K, e, idx, cx, cy, cz);
   // ---- _calculate_reward (:198-231)
   const T dx = e.px - cx, dy = e.py - cy, dz = e.pz - cz;
   const T dist = sqrt_(dot3_(dx, dy, dz, dx, dy, dz));                    // :204
@@ -230,8 +239,8 @@ __device__ __forceinline__ uint32_t task_step(const Params<T>& P, Env<T>& e, T& 
   bool returned = false;
   if (dist < T(0.1)) {                                                  // :147
     if (!fwr) { idx += 1; reward += T(100); }                           // :148-150
-    if (idx >= P.K) {                                                   // :153 (else: next waypoint, fall through)
-      idx = P.K;                                                        // waypoint_index == len(list)
+    if (idx >= K) {                                                     // :153 (else: next waypoint, fall through)
+      idx = K;                                                          // waypoint_index == len(list)
       // roll, pitch, yaw (utils2/utils.py:4-9 closed form); only the hold-phase bonuses use them
       const T roll = atan2_(T(2) * fma_(e.qw, e.qx, e.qy * e.qz), fma_(T(-2), fma_(e.qx, e.qx, e.qy * e.qy), T(1)));
       T sp = T(2) * fma_(e.qw, e.qy, -(e.qz * e.qx));
@@ -292,8 +301,8 @@ __device__ __forceinline__ float u01(uint32_t r) { return float(r >> 8) * 5.9604
 
 // WaypointQuadEnv.reset (rl_env_scaledObs.py:40-79) with the DESIGN.md draw table.  All draws
 // are formed in fp32 with explicit fmaf so the CPU oracle reproduces them bit for bit.
-template <typename T>
-__device__ __forceinline__ void reset_env(const Params<T>& P, Env<T>& e, int64_t gid) {
+template <typename T, int KW>
+__device__ __forceinline__ void reset_env(const ColdParams& P, int K, Env<T, KW>& e, int64_t gid) {
   uint32_t r[12];
 #pragma unroll
   for (uint32_t b = 0; b < 3; b++)
@@ -310,15 +319,15 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, Env<T>& e, int64_t
   const float fyaw = fmaf(2.0f * PIF, u01(r[11]), -PIF);                // :72
   const int kind = sel0 < 0.3f ? 0 : (sel1 < 0.6f ? 1 : 2);
 #pragma unroll
-  for (int k = 1; k <= AMENV_MAX_WAYPOINTS; k++) {
-    if (k > P.K) break;
+  for (int k = 1; k <= KW; k++) {
+    if (k > K) break;
     float wx, wy, wz;
     if (kind == 2) {                                                    // helical, utils2/utils.py:61-95
       wx = fmaf(0.8f, P.traj_cos[k - 1], sx);
       wy = fmaf(0.8f, P.traj_sin[k - 1], sy);
       wz = fmaxf(fmaf(float(k), 0.4f, sz), 0.2f);
     } else {                                                            // linear / curved, :12-57
-      const float t = float(k) / float(P.K);
+      const float t = float(k) / float(K);
       wx = fmaf(t, ex - sx, sx); wy = fmaf(t, ey - sy, sy); wz = fmaf(t, ez - sz, sz);
       if (kind == 1) {
         const float s = P.traj_sin[k - 1];

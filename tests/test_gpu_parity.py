@@ -285,8 +285,9 @@ def test_rollout_kernel_equals_single_steps(amd):
     rng = np.random.RandomState(2)
     a = rng.uniform([0, -1, -1, -1], [2, 1, 1, 1], (T, n, 4)).astype(np.float32)
     a[:, :, 1:] *= 0.1
+    a[:, ::7, 0] = 0.0  # every 7th env free-falls: crashes and auto-resets inside the window
     at = torch.from_numpy(a).cuda()
-    e1 = amd.GpuWaypointEnv(n, seed=3); e2 = amd.GpuWaypointEnv(n, seed=3)
+    e1 = amd.GpuWaypointEnv(n, seed=3, max_episode_steps=40); e2 = amd.GpuWaypointEnv(n, seed=3, max_episode_steps=40)
     e1.reset(); e2.reset()
     ro = e1.rollout(at)
     for t in range(T):

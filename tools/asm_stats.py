@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rl-aerial-manipulator_amd", "csrc")
 out = "/tmp/amenv.s"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-gpu-rdc", "-S",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-gpu-rdc", "-S",
                        "--cuda-device-only", "-o", out, "amenv_capi.hip"], cwd=CSRC)
 filt = sys.argv[1] if len(sys.argv) > 1 else "step_kernelIf"
 lines = open(out).read().split("\n")
