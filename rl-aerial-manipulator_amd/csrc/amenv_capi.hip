@@ -35,6 +35,8 @@ static thread_local std::string g_create_err;
 
 namespace {
 
+constexpr int kStatsWords = kStampBase + kStampWaves * kStampSlots;  // totals + diagnostic stamp area
+
 struct DeviceGuard {
   int prev = -1, dev;
   explicit DeviceGuard(int d) : dev(d) {
@@ -162,7 +164,7 @@ HotParams<T, NR> make_hot(const amenv& e) {
   P.mass_f = float(v.mass); P.g_f = float(v.g); P.mscale_f = float(v.moment_scale);
   P.n_rotors = v.n_rotors; P.substeps = ns;
   P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit;
-  P.flags = c.flags; P.n = c.num_envs; P.K = c.task.num_waypoints; P.tile_bytes = e.tile_bytes;
+  P.flags = c.flags; P.K = c.task.num_waypoints;
   return P;
 }
 
@@ -207,12 +209,16 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   const int bs = e.block, n_pad = e.n_tiles * 64;
   const dim3 grid((n_pad + bs - 1) / bs), block(bs);
   const size_t lds = size_t(bs) * kObsDim * sizeof(float);
+  const StepTail tl{io.terminal_obs, io.ep_return, io.ep_len, io.stats};
+  const uint32_t tb = e.tile_bytes;
+  const int32_t n = e.cfg.num_envs;
   if (T_steps > 0) {
-    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW>), grid, block, lds, s, P, C, e.blob, io, T_steps);
+    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C);
   } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
-    hipExtLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, P, C, e.blob, io);
+    hipExtLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward, io.done,
+                          io.info, tl, P, C);
   } else {
-    hipLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, P, C, e.blob, io);
+    hipLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C);
   }
   return hipGetLastError();
 }
@@ -323,9 +329,9 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   DeviceGuard g(device);
   hipError_t s;
   if ((s = hipMalloc(&e->blob, e->blob_bytes)) != hipSuccess ||
-      (s = hipMalloc((void**)&e->stats, sizeof(unsigned long long) * S_COUNT)) != hipSuccess ||
+      (s = hipMalloc((void**)&e->stats, sizeof(unsigned long long) * kStatsWords)) != hipSuccess ||
       (s = hipMemset(e->blob, 0, e->blob_bytes)) != hipSuccess ||
-      (s = hipMemset(e->stats, 0, sizeof(unsigned long long) * S_COUNT)) != hipSuccess ||
+      (s = hipMemset(e->stats, 0, sizeof(unsigned long long) * kStatsWords)) != hipSuccess ||
       // give the padding lanes of the last tile a valid state (real envs stay untouched: episode 0)
       (s = (cfg->dtype == AMENV_F64 ? launch_reset<double>(*e, nullptr, nullptr, 1, nullptr) : launch_reset<float>(*e, nullptr, nullptr, 1, nullptr))) != hipSuccess ||
       (s = hipDeviceSynchronize()) != hipSuccess) {
@@ -461,5 +467,34 @@ int amenv_stats_read(amenv* e, amenv_stats* out, int reset, void* stream) {
   if (reset) e->steps = 0;
   return AMENV_OK;
 }
+
+#ifdef AMENV_STAMPS
+// diagnostic build only: an empty kernel with the step kernel's grid, to measure the dependent-launch floor
+__global__ void noop_kernel(void* blob, uint32_t tile_bytes, int32_t n, unsigned long long* sink) {
+  if (n < 0) sink[0] = tile_bytes;
+}
+__global__ void touch_kernel(void* blob, uint32_t tile_bytes, int32_t n, unsigned long long* sink) {
+  // one 16-B load + one 16-B store per lane: the minimal memory round trip
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int4* p = reinterpret_cast<int4*>(static_cast<char*>(blob) + size_t(i >> 6) * tile_bytes) + (threadIdx.x & 63);
+  int4 v = *p; v.w ^= 0; *p = v;
+}
+int amenv_debug_noop(amenv* e, int which, int block, void* stream) {
+  DeviceGuard g(e->device);
+  const int bs = block > 0 ? block : e->block, n_pad = e->n_tiles * 64;
+  if (which == 0) hipLaunchKernelGGL(noop_kernel, dim3((n_pad + bs - 1) / bs), dim3(bs), 0, (hipStream_t)stream, e->blob, e->tile_bytes, e->cfg.num_envs, e->stats);
+  else hipLaunchKernelGGL(touch_kernel, dim3((n_pad + bs - 1) / bs), dim3(bs), 0, (hipStream_t)stream, e->blob, e->tile_bytes, e->cfg.num_envs, e->stats);
+  AMENV_HIP(e, hipGetLastError());
+  return AMENV_OK;
+}
+
+// diagnostic build only: copy the per-wave s_memtime stamps of the last step launch to host (synchronises)
+int amenv_debug_stamps(amenv* e, unsigned long long* host_out /*[64][8]*/) {
+  DeviceGuard g(e->device);
+  AMENV_HIP(e, hipDeviceSynchronize());
+  AMENV_HIP(e, hipMemcpy(host_out, e->stats + kStampBase, sizeof(unsigned long long) * kStampWaves * kStampSlots, hipMemcpyDeviceToHost));
+  return AMENV_OK;
+}
+#endif
 
 }  // extern "C"

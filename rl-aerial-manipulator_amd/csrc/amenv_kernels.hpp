@@ -2,11 +2,12 @@
 //
 // Data layout in HBM (DESIGN.md "Layout")
 //   state blob : tiles of 64 environments (one wavefront each), tile t at byte t * tile_bytes:
-//                  [4 int fields   ][64 lanes] i32      offsets 0, 256, 512, 768
-//                  [NF float fields][64 lanes] T        offset 1024 + f * 64 * sizeof(T)
-//                One wave's whole state is ONE contiguous block (4.9 KiB for fp32, K = 1); every field
-//                access is a fully coalesced 256-B (fp32) wave transaction whose field offset is an
-//                instruction immediate: one base address per lane, no per-field address arithmetic.
+//                  [int4 plane ][64 lanes] {step, counter, flags, episode}          offset 0, 16 B/lane
+//                  [G float4 groups][64 lanes] {field 4g .. 4g+3} of type T          offset 1024 + g*64*4*sizeof(T)
+//                Field order = enum amenv_float_field: the 13 rigid-body states + final_yaw + last_distance +
+//                ep_return fill groups 0..3 exactly; waypoints follow.  Every access is 16 B per lane
+//                (fp32): a wave moves 1 KiB per instruction, fully coalesced, field-group offsets are
+//                instruction immediates.  fp32/K=1: 6 loads + 5 stores per env-step instead of 22 + 18 dwords.
 //   actions    : f32 [N][4]   one float4 per lane, coalesced
 //   obs        : f32 [N][20]  row-major for the policy MLP: rows are staged through LDS and written
 //                             as contiguous 1-KiB float4 wave stores
@@ -19,65 +20,74 @@ namespace amenv_dev {
 
 enum StatSlot { S_EPISODES = 0, S_TERMINATED, S_TRUNCATED, S_SUCCESS, S_CRASHED, S_OOB, S_NONFINITE, S_LENGTH, S_RETURN_Q10, S_COUNT };
 
-constexpr uint32_t kIntBytes = AMENV_I_NFIELDS * 64 * sizeof(int32_t);  // 1024
+constexpr uint32_t kIntBytes = 64 * 4 * sizeof(int32_t);  // 1024: one int4 per lane
 
-__host__ __device__ inline uint32_t tile_bytes_for(int n_float_fields, int tsize) { return kIntBytes + uint32_t(n_float_fields) * 64u * uint32_t(tsize); }
+template <typename T> struct alignas(4 * sizeof(T)) Vec4 { T a, b, c, d; };
+
+__host__ __device__ inline int n_groups_for(int n_float_fields) { return (n_float_fields + 3) / 4; }
+__host__ __device__ inline uint32_t tile_bytes_for(int n_float_fields, int tsize) {
+  return kIntBytes + uint32_t(n_groups_for(n_float_fields)) * 64u * 4u * uint32_t(tsize);
+}
 
 // byte address of the tile that holds env i
 __device__ __forceinline__ const char* tile_base(const void* blob, uint32_t tile_bytes, int i) {
   return static_cast<const char*>(blob) + size_t(i >> 6) * tile_bytes;
 }
-template <typename T> __device__ __forceinline__ T* fptr(char* tile, int lane, int field) {
-  return reinterpret_cast<T*>(tile + kIntBytes + size_t(field) * 64 * sizeof(T)) + lane;
+template <typename T> __device__ __forceinline__ Vec4<T>* gptr(char* tile, int lane, int group) {
+  return reinterpret_cast<Vec4<T>*>(tile + kIntBytes + size_t(group) * 64 * sizeof(Vec4<T>)) + lane;
 }
-__device__ __forceinline__ int32_t* iptr(char* tile, int lane, int field) { return reinterpret_cast<int32_t*>(tile + size_t(field) * 256) + lane; }
+__device__ __forceinline__ int4* iptr4(char* tile, int lane) { return reinterpret_cast<int4*>(tile) + lane; }
+// scalar views (transposes, lazy episode load)
+template <typename T> __device__ __forceinline__ T* fptr(char* tile, int lane, int field) {
+  return reinterpret_cast<T*>(gptr<T>(tile, lane, field >> 2)) + (field & 3);
+}
+__device__ __forceinline__ int32_t* iptr(char* tile, int lane, int field) { return reinterpret_cast<int32_t*>(iptr4(tile, lane)) + field; }
+
+static_assert(AMENV_F_WP0 == 16 && AMENV_F_FINAL_YAW == 13 && AMENV_F_LAST_DISTANCE == 14 && AMENV_F_EP_RETURN == 15, "groups 0..3 = 16 hot fields");
 
 template <typename T, int KW>
 __device__ __forceinline__ void load_env(int K, const char* tile_c, int lane, Env<T, KW>& e) {
   char* tile = const_cast<char*>(tile_c);
-  e.px = *fptr<T>(tile, lane, 0); e.py = *fptr<T>(tile, lane, 1); e.pz = *fptr<T>(tile, lane, 2);
-  e.vx = *fptr<T>(tile, lane, 3); e.vy = *fptr<T>(tile, lane, 4); e.vz = *fptr<T>(tile, lane, 5);
-  e.qw = *fptr<T>(tile, lane, 6); e.qx = *fptr<T>(tile, lane, 7); e.qy = *fptr<T>(tile, lane, 8); e.qz = *fptr<T>(tile, lane, 9);
-  e.wx = *fptr<T>(tile, lane, 10); e.wy = *fptr<T>(tile, lane, 11); e.wz = *fptr<T>(tile, lane, 12);
-  e.final_yaw = *fptr<T>(tile, lane, AMENV_F_FINAL_YAW);
-  e.last_distance = *fptr<T>(tile, lane, AMENV_F_LAST_DISTANCE);
-  e.ep_return = *fptr<T>(tile, lane, AMENV_F_EP_RETURN);
+  const Vec4<T> g0 = *gptr<T>(tile, lane, 0), g1 = *gptr<T>(tile, lane, 1), g2 = *gptr<T>(tile, lane, 2), g3 = *gptr<T>(tile, lane, 3);
+  const int4 iv = *iptr4(tile, lane);
+  e.px = g0.a; e.py = g0.b; e.pz = g0.c; e.vx = g0.d;
+  e.vy = g1.a; e.vz = g1.b; e.qw = g1.c; e.qx = g1.d;
+  e.qy = g2.a; e.qz = g2.b; e.wx = g2.c; e.wy = g2.d;
+  e.wz = g3.a; e.final_yaw = g3.b; e.last_distance = g3.c; e.ep_return = g3.d;
+  // waypoint k = fields 16+3k .. 18+3k: contiguous floats starting in group 4
+  T w[((3 * KW + 3) / 4) * 4];
 #pragma unroll
-  for (int k = 0; k < KW; k++) {
-    if (k < K) {
-      e.wp[k][0] = *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * k + 0); e.wp[k][1] = *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * k + 1);
-      e.wp[k][2] = *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * k + 2);
-    } else {
-      e.wp[k][0] = e.wp[k][1] = e.wp[k][2] = T(0);
-    }
+  for (int g = 0; g < (3 * KW + 3) / 4; g++) {
+    Vec4<T> v{T(0), T(0), T(0), T(0)};
+    if (3 * K > 4 * g) v = *gptr<T>(tile, lane, 4 + g);
+    w[4 * g] = v.a; w[4 * g + 1] = v.b; w[4 * g + 2] = v.c; w[4 * g + 3] = v.d;
   }
-  e.step = *iptr(tile, lane, AMENV_I_STEP); e.counter = *iptr(tile, lane, AMENV_I_COUNTER); e.flags = *iptr(tile, lane, AMENV_I_FLAGS);
-  e.episode = 0;  // the episode counter is only needed by a reset: loaded there
+#pragma unroll
+  for (int k = 0; k < KW; k++) { e.wp[k][0] = w[3 * k]; e.wp[k][1] = w[3 * k + 1]; e.wp[k][2] = w[3 * k + 2]; }
+  e.step = iv.x; e.counter = iv.y; e.flags = iv.z; e.episode = iv.w;
 }
 
-// per-step mutable part of the state
+// per-step store: groups 0..3 + the int4 (final_yaw and episode are rewritten with their unchanged values)
 template <typename T, int KW>
 __device__ __forceinline__ void store_env_step(char* tile, int lane, const Env<T, KW>& e) {
-  *fptr<T>(tile, lane, 0) = e.px; *fptr<T>(tile, lane, 1) = e.py; *fptr<T>(tile, lane, 2) = e.pz;
-  *fptr<T>(tile, lane, 3) = e.vx; *fptr<T>(tile, lane, 4) = e.vy; *fptr<T>(tile, lane, 5) = e.vz;
-  *fptr<T>(tile, lane, 6) = e.qw; *fptr<T>(tile, lane, 7) = e.qx; *fptr<T>(tile, lane, 8) = e.qy; *fptr<T>(tile, lane, 9) = e.qz;
-  *fptr<T>(tile, lane, 10) = e.wx; *fptr<T>(tile, lane, 11) = e.wy; *fptr<T>(tile, lane, 12) = e.wz;
-  *fptr<T>(tile, lane, AMENV_F_LAST_DISTANCE) = e.last_distance;
-  *fptr<T>(tile, lane, AMENV_F_EP_RETURN) = e.ep_return;
-  *iptr(tile, lane, AMENV_I_STEP) = e.step; *iptr(tile, lane, AMENV_I_COUNTER) = e.counter; *iptr(tile, lane, AMENV_I_FLAGS) = e.flags;
+  *gptr<T>(tile, lane, 0) = Vec4<T>{e.px, e.py, e.pz, e.vx};
+  *gptr<T>(tile, lane, 1) = Vec4<T>{e.vy, e.vz, e.qw, e.qx};
+  *gptr<T>(tile, lane, 2) = Vec4<T>{e.qy, e.qz, e.wx, e.wy};
+  *gptr<T>(tile, lane, 3) = Vec4<T>{e.wz, e.final_yaw, e.last_distance, e.ep_return};
+  *iptr4(tile, lane) = make_int4(e.step, e.counter, e.flags, e.episode);
 }
 
-// per-episode constants, written only by lanes that were reset
+// per-episode constants (waypoints), written only by lanes that were reset
 template <typename T, int KW>
 __device__ __forceinline__ void store_env_episode(int K, char* tile, int lane, const Env<T, KW>& e) {
-  *fptr<T>(tile, lane, AMENV_F_FINAL_YAW) = e.final_yaw;
+  T w[((3 * KW + 3) / 4) * 4];
 #pragma unroll
-  for (int k = 0; k < KW; k++)
-    if (k < K) {
-      *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * k + 0) = e.wp[k][0]; *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * k + 1) = e.wp[k][1];
-      *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * k + 2) = e.wp[k][2];
-    }
-  *iptr(tile, lane, AMENV_I_EPISODE) = e.episode;
+  for (int j = 0; j < ((3 * KW + 3) / 4) * 4; j++) w[j] = T(0);
+#pragma unroll
+  for (int k = 0; k < KW; k++) { w[3 * k] = e.wp[k][0]; w[3 * k + 1] = e.wp[k][1]; w[3 * k + 2] = e.wp[k][2]; }
+#pragma unroll
+  for (int g = 0; g < (3 * KW + 3) / 4; g++)
+    if (3 * K > 4 * g) *gptr<T>(tile, lane, 4 + g) = Vec4<T>{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
 }
 
 // Stage this lane's 80-B observation row in LDS.  Row stride 80 B: the 8 lanes of a
@@ -95,24 +105,25 @@ __device__ __forceinline__ void flush_obs(const float* lds, float* __restrict__ 
   float4* d = reinterpret_cast<float4*>(obs_block);
   const int nvec = rows_valid * (kObsDim / 4);
   const int bs = int(blockDim.x);
+  // all five LDS reads first (unconditional: the staging area is always blockDim.x rows), then the
+  // predicated stores: one LDS round trip instead of five dependent ones
+  float4 v[kObsDim / 4];
+#pragma unroll
+  for (int j = 0; j < kObsDim / 4; j++) v[j] = s[j * bs + int(threadIdx.x)];
 #pragma unroll
   for (int j = 0; j < kObsDim / 4; j++) {
     const int f = j * bs + int(threadIdx.x);
-    if (f < nvec) d[f] = s[f];
+    if (f < nvec) d[f] = v[j];
   }
 }
 
-__device__ __forceinline__ long long wave_sum(long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// Monitor-style running totals: ballot+popcount for the counters, a shuffle reduction only in
-// waves that finished an episode this step, one atomic per wave and counter.
+// Monitor-style running totals.  Episode ends are rare (usually zero or one lane of a wave per step), so:
+// ballot + popcount for the counters, a SCALAR loop over the finished lanes (v_readlane) for the length /
+// return sums -- no cross-lane shuffles -- and one no-return atomic per wave and non-zero counter.
+// Called right after the state machine so the atomics drain while the wave stores its outputs.
 __device__ __forceinline__ void accumulate_stats(unsigned long long* __restrict__ stats, uint32_t bits, bool is_done, int ep_len,
                                                  float ep_ret) {
-  const unsigned long long m_done = __ballot(is_done);
+  unsigned long long m_done = __ballot(is_done);
   if (m_done == 0ull) return;  // wave-uniform
   const unsigned long long m_term = __ballot(is_done && (bits & AMENV_INFO_TERMINATED));
   const unsigned long long m_trunc = __ballot(is_done && (bits & AMENV_INFO_TRUNCATED) && !(bits & AMENV_INFO_TERMINATED));
@@ -120,12 +131,18 @@ __device__ __forceinline__ void accumulate_stats(unsigned long long* __restrict_
   const unsigned long long m_crash = __ballot(is_done && (bits & AMENV_INFO_CRASHED));
   const unsigned long long m_oob = __ballot(is_done && (bits & AMENV_INFO_OOB));
   const unsigned long long m_nf = __ballot(is_done && (bits & AMENV_INFO_NONFINITE));
-  const float r = is_done ? ep_ret : 0.0f;
-  const long long q = __builtin_isfinite(r) ? llrintf(r * 1024.0f) : 0ll;
-  const long long len_sum = wave_sum(is_done ? (long long)ep_len : 0ll);
-  const long long ret_sum = wave_sum(q);
+  const int n_done = __popcll(m_done);
+  long long len_sum = 0, ret_sum = 0;
+  const int ret_bits = __float_as_int(ep_ret);
+  while (m_done) {  // scalar loop: one iteration per finished lane, in lane order (deterministic)
+    const int l = __builtin_ctzll(m_done);
+    m_done &= m_done - 1;
+    len_sum += __builtin_amdgcn_readlane(ep_len, l);
+    const float r = __int_as_float(__builtin_amdgcn_readlane(ret_bits, l));
+    ret_sum += __builtin_isfinite(r) ? (long long)__builtin_rintf(r * 1024.0f) : 0ll;
+  }
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&stats[S_EPISODES], (unsigned long long)__popcll(m_done));
+    atomicAdd(&stats[S_EPISODES], (unsigned long long)n_done);
     if (m_term) atomicAdd(&stats[S_TERMINATED], (unsigned long long)__popcll(m_term));
     if (m_trunc) atomicAdd(&stats[S_TRUNCATED], (unsigned long long)__popcll(m_trunc));
     if (m_succ) atomicAdd(&stats[S_SUCCESS], (unsigned long long)__popcll(m_succ));
@@ -137,6 +154,10 @@ __device__ __forceinline__ void accumulate_stats(unsigned long long* __restrict_
   }
 }
 
+// The step/rollout kernels take what a wave needs before it can issue its first load as LEADING SCALAR
+// arguments (blob, tile_bytes, n, actions, obs, reward, done, info = 14 dwords): gfx950 preloads the
+// first 16 kernarg dwords into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16; struct
+// arguments are not eligible), so no scalar-load round trip sits in front of the state loads.
 struct StepIO {
   const float4* actions;  // [N] (or [T][N] for rollout)
   float* obs;             // [N][20]
@@ -174,7 +195,6 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
       if (io.ep_len) io.ep_len[i] = ep_len_out;
     }
     if (P.flags & AMENV_FLAG_AUTO_RESET) {
-      if (!have_episode) e.episode = *iptr(tile, lane, AMENV_I_EPISODE);
       reset_env<T, KW>(C, K, e, C.gid0 + i);
       observe<T, KW>(K, e, o);
       bits |= AMENV_INFO_WAS_RESET;
@@ -187,21 +207,56 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
 // Workgroup size is a launch parameter (64..256, multiple of 64): LDS staging area = blockDim.x rows.
 // The state blob holds whole tiles, so padding lanes (i >= n) of the last wave run like real
 // environments on their own (valid) slots; only their outputs are masked.
+// Diagnostic build only (-DAMENV_STAMPS, tools/stamp_profile.py): s_memtime stamps at phase boundaries,
+// written by lane 0 of each wave into a buffer of their own behind the stats words.  No stamp executes
+// in the product build and no output value is computed from one.
+#ifdef AMENV_STAMPS
+#define AMENV_STAMP(k)                                                                       \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    stamps_[k] = t_;                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#define AMENV_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define AMENV_STAMP(k)
+#define AMENV_STAMP_DRAIN()
+#endif
+constexpr int kStampSlots = 8, kStampWaves = 64, kStampBase = 16;
+
+struct StepTail { float* terminal_obs; float* ep_return; int32_t* ep_len; unsigned long long* stats; };
+struct Head { void* blob; uint32_t tile_bytes; int32_t n; };
+
 template <typename T, int NROT, int KW>
-__global__ __launch_bounds__(256) void step_kernel(const HotParams<T, NROT> P, const ColdParams C, void* __restrict__ blob, const StepIO io) {
+__global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+                                                   float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                   uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C) {
+#ifdef AMENV_STAMPS
+  unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  AMENV_STAMP(0);
+  const Head hd{blob, tile_bytes, n_envs};
+  const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int BS = int(blockDim.x);
   const int i = blockIdx.x * BS + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const bool active = i < P.n;
-  char* tile = const_cast<char*>(tile_base(blob, P.tile_bytes, i));
+  const bool active = i < hd.n;
+  char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
   const int K = KW == 1 ? 1 : P.K;
   Env<T, KW> e;
   load_env<T, KW>(K, tile, lane, e);
-  const float4 a = active ? io.actions[i] : make_float4(1.0f, 0.f, 0.f, 0.f);
+  const float4 a = io.actions[min(i, hd.n - 1)];  // padding lanes re-read the last env's action: no exec branch in the prologue
+  AMENV_STAMP(1);          // loads issued
+  AMENV_STAMP_DRAIN();
+  AMENV_STAMP(2);          // loads landed
   T reward; float o[kObsDim]; bool was_reset; int ep_len; float ep_ret;
   uint32_t bits = step_lane<T, NROT, KW>(P, C, e, a, i, active, reward, o, io, tile, lane, false, was_reset, ep_len, ep_ret);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+  AMENV_STAMP(3);          // dynamics + task + obs computed
+  accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
   store_env_step<T, KW>(tile, lane, e);
   if (was_reset) store_env_episode<T, KW>(K, tile, lane, e);
   if (active) {
@@ -209,39 +264,53 @@ __global__ __launch_bounds__(256) void step_kernel(const HotParams<T, NROT> P, c
     io.done[i] = is_done ? 1 : 0;
     io.info[i] = bits;
   }
+  AMENV_STAMP(4);          // state/outputs stores issued
   stage_obs(lds + threadIdx.x * kObsDim, o);
   __syncthreads();
   const int row0 = blockIdx.x * BS;
-  const int rows = min(BS, P.n - row0);
+  const int rows = min(BS, hd.n - row0);
   flush_obs(lds, io.obs + size_t(row0) * kObsDim, rows);
-  accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
+  AMENV_STAMP(5);          // obs flushed
+  AMENV_STAMP(6);
+#ifdef AMENV_STAMPS
+  AMENV_STAMP_DRAIN();
+  AMENV_STAMP(7);          // all stores acknowledged
+  const int wave = (blockIdx.x * BS + threadIdx.x) >> 6;
+  if (lane == 0 && wave < kStampWaves)
+    for (int k = 0; k < kStampSlots; k++) io.stats[kStampBase + wave * kStampSlots + k] = stamps_[k];
+#endif
 }
 
 // n_steps control steps per launch with open-loop actions [T][N][4]; per-step outputs [T][N]...
 // State stays in registers across steps: HBM traffic per env-step drops to action + outputs.
 template <typename T, int NROT, int KW>
-__global__ __launch_bounds__(256) void rollout_kernel(const HotParams<T, NROT> P, const ColdParams C, void* __restrict__ blob,
-                                                      const StepIO io, int n_steps) {
+__global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+                                                      float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                      uint32_t* __restrict__ info, int n_steps, const StepTail tl, const HotParams<T, NROT> P,
+                                                      const ColdParams C) {
+  const Head hd{blob, tile_bytes, n_envs};
+  const StepIO io{actions, obs, reward_out, done, info, nullptr, nullptr, nullptr, tl.stats};
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int BS = int(blockDim.x);
   const int i = blockIdx.x * BS + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const bool active = i < P.n;
+  const bool active = i < hd.n;
   const int row0 = blockIdx.x * BS;
-  const int rows = min(BS, P.n - row0);
-  const size_t n = size_t(P.n);
-  char* tile = const_cast<char*>(tile_base(blob, P.tile_bytes, i));
+  const int rows = min(BS, hd.n - row0);
+  const size_t n = size_t(hd.n);
+  char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
   const int K = KW == 1 ? 1 : P.K;
   Env<T, KW> e;
   load_env<T, KW>(K, tile, lane, e);
   bool any_reset = false;
   StepIO io_t = io; io_t.terminal_obs = nullptr; io_t.ep_return = nullptr; io_t.ep_len = nullptr;
   for (int t = 0; t < n_steps; t++) {
-    const float4 a = active ? io.actions[size_t(t) * n + i] : make_float4(1.0f, 0.f, 0.f, 0.f);
+    const float4 a = io.actions[size_t(t) * n + min(i, hd.n - 1)];
     T reward; float o[kObsDim]; bool was_reset; int ep_len; float ep_ret;
     uint32_t bits = step_lane<T, NROT, KW>(P, C, e, a, i, active, reward, o, io_t, tile, lane, any_reset, was_reset, ep_len, ep_ret);
     any_reset |= was_reset;
     const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+    accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
     if (active) {
       if (io.reward) reinterpret_cast<T*>(io.reward)[size_t(t) * n + i] = reward;
       if (io.done) io.done[size_t(t) * n + i] = is_done ? 1 : 0;
@@ -253,7 +322,6 @@ __global__ __launch_bounds__(256) void rollout_kernel(const HotParams<T, NROT> P
       flush_obs(lds, io.obs + (size_t(t) * n + row0) * kObsDim, rows);
       __syncthreads();
     }
-    accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
   }
   store_env_step<T, KW>(tile, lane, e);
   if (any_reset) store_env_episode<T, KW>(K, tile, lane, e);
@@ -272,7 +340,6 @@ __global__ void reset_kernel(int n, int K, uint32_t tile_bytes, const ColdParams
   load_env<T, AMENV_MAX_WAYPOINTS>(K, tile, lane, e);
   const bool do_reset = active ? (!pad_only && (!mask || mask[i])) : true;  // pad_only: amenv_create's init pass
   if (do_reset) {
-    e.episode = *iptr(tile, lane, AMENV_I_EPISODE);
     reset_env<T, AMENV_MAX_WAYPOINTS>(C, K, e, C.gid0 + i);
     store_env_step<T, AMENV_MAX_WAYPOINTS>(tile, lane, e);
     store_env_episode<T, AMENV_MAX_WAYPOINTS>(K, tile, lane, e);

@@ -43,9 +43,7 @@ struct HotParams {
   int32_t n_rotors;                 // used only by the generic (NR = AMENV_MAX_ROTORS) instantiation
   int32_t substeps, max_steps, counter_limit;
   uint32_t flags;
-  int32_t n;                        // envs on this device
   int32_t K;                        // waypoints per episode (<= KW of the instantiation)
-  uint32_t tile_bytes;              // bytes of one 64-env state tile
 };
 
 // Parameters only the reset path needs (cold: loaded when a lane actually resets).
@@ -69,6 +67,8 @@ __device__ __forceinline__ float atan2_(float a, float b) { return atan2f(a, b);
 __device__ __forceinline__ double atan2_(double a, double b) { return atan2(a, b); }
 __device__ __forceinline__ float asin_(float a) { return asinf(a); }
 __device__ __forceinline__ double asin_(double a) { return asin(a); }
+__device__ __forceinline__ float clamp_(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }  // v_med3_f32
+__device__ __forceinline__ double clamp_(double x, double lo, double hi) { return __builtin_fmax(__builtin_fmin(x, hi), lo); }
 __device__ __forceinline__ float abs_(float a) { return fabsf(a); }
 __device__ __forceinline__ double abs_(double a) { return fabs(a); }
 __device__ __forceinline__ bool finite_(float a) { return __builtin_isfinite(a); }
@@ -137,13 +137,13 @@ __device__ __forceinline__ void dynamics(const HotParams<T, NROT>& P, Env<T, KW>
   for (int r = 0; r < NROT; r++) {
     if (NROT == AMENV_MAX_ROTORS && r >= P.n_rotors) break;  // generic instantiation: runtime rotor count
     T t = fma_(P.alloc[r][0], u0, fma_(P.alloc[r][1], u1, fma_(P.alloc[r][2], u2, P.alloc[r][3] * u3)));
-    t = t < P.tmax[r] ? t : P.tmax[r];
-    t = t > P.tmin[r] ? t : P.tmin[r];
+    t = clamp_(t, P.tmin[r], P.tmax[r]);   // np.maximum(np.minimum(t, max), min), quadcopter.py:110
     F = F + t; Mx = fma_(P.mixm[0][r], t, Mx); My = fma_(P.mixm[1][r], t, My); Mz = fma_(P.mixm[2][r], t, Mz);
   }
   const T Fm = F * P.inv_mass;
   const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
-  for (int it = 0; it < P.substeps; it++) {
+  int it = 0;
+  do {  // substeps >= 1 (validated at create): no loop guard in front of the first stage
     const Deriv<T> k1 = rhs<T>(P, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz, Fm, Mx, My, Mz);
     const Deriv<T> k2 = rhs<T>(P, fma_(hh, k1.ax, e.vx), fma_(hh, k1.ay, e.vy), fma_(hh, k1.az, e.vz), fma_(hh, k1.dqw, e.qw),
                             fma_(hh, k1.dqx, e.qx), fma_(hh, k1.dqy, e.qy), fma_(hh, k1.dqz, e.qz), fma_(hh, k1.dwx, e.wx),
@@ -161,7 +161,7 @@ __device__ __forceinline__ void dynamics(const HotParams<T, NROT>& P, Env<T, KW>
     AMENV_RK4(qw, dqw); AMENV_RK4(qx, dqx); AMENV_RK4(qy, dqy); AMENV_RK4(qz, dqz);
     AMENV_RK4(wx, dwx); AMENV_RK4(wy, dwy); AMENV_RK4(wz, dwz);
 #undef AMENV_RK4
-  }
+  } while (++it < P.substeps);
   const T rn = rsqrt_(fma_(e.qw, e.qw, fma_(e.qx, e.qx, fma_(e.qy, e.qy, e.qz * e.qz))));   // :114
   e.qw *= rn; e.qx *= rn; e.qy *= rn; e.qz *= rn;
 }
@@ -288,8 +288,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
                                               uint32_t* out) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint64_t p0 = uint64_t(0xD2511F53u) * c0, p1 = uint64_t(0xCD9E8D57u) * c2;  // one v_mad_u64_u32 each
+    const uint32_t h0 = uint32_t(p0 >> 32), l0 = uint32_t(p0), h1 = uint32_t(p1 >> 32), l1 = uint32_t(p1);
     const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

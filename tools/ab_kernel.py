@@ -24,7 +24,7 @@ def child(args):
         env = amd.GpuWaypointEnv(n, vehicle=args.vehicle, seed=0, block_size=args.block_size)
         env.reset()
         g = torch.Generator(device="cuda").manual_seed(1)
-        ring = torch.randn(64, n, 4, device="cuda", generator=g) * 0.1
+        ring = torch.randn(64, n, 4, device="cuda", generator=g) * (0.1 if args.ring == "random" else 0.0)
         ring[..., 0] += 1.0
         ring = ring.clamp(min=-1, max=2).contiguous()
         for t in range(64):
@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--vehicle", default="hexa")
     ap.add_argument("--block-size", type=int, default=0)
     ap.add_argument("--block-sizes", nargs="+", type=int, default=None)
+    ap.add_argument("--ring", default="random", choices=["random", "hover"])
     ap.add_argument("--child", action="store_true")
     args = ap.parse_args()
     if args.child:
@@ -71,7 +72,7 @@ def main():
     for r in range(args.rounds):
         for lib, bs in variants:
             env = dict(os.environ, AMENV_LIB=os.path.abspath(lib))
-            cmd = [sys.executable, os.path.abspath(__file__), "--child", "--vehicle", args.vehicle, "--block-size", str(bs), "--envs"] + [str(n) for n in args.envs]
+            cmd = [sys.executable, os.path.abspath(__file__), "--child", "--vehicle", args.vehicle, "--block-size", str(bs), "--ring", args.ring, "--envs"] + [str(n) for n in args.envs]
             o = subprocess.run(cmd, env=env, capture_output=True, text=True)
             line = [l for l in o.stdout.splitlines() if l.startswith("{")]
             if not line:

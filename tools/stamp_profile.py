@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""In-kernel phase timing of the step kernel from a -DAMENV_STAMPS diagnostic build (GPU box).
+  AMENV_LIB=<stamps.so> python tools/stamp_profile.py --envs 4096
+Prints the median over launches and waves of each phase's share (shader-clock cycles, s_memtime)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--vehicle", default="hexa")
+ap.add_argument("--launches", type=int, default=100)
+a = ap.parse_args()
+import torch
+
+import rl_aerial_manipulator_amd as amd
+
+env = amd.GpuWaypointEnv(a.envs, vehicle=a.vehicle, seed=0)
+env.reset()
+lib = C.CDLL(amd._lib.LIB_PATH)
+lib.amenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+g = torch.Generator(device="cuda").manual_seed(1)
+ring = torch.randn(16, a.envs, 4, device="cuda", generator=g) * 0.1
+ring[..., 0] += 1.0
+ring = ring.clamp(min=-1, max=2).contiguous()
+names = ["entry->loads issued", "loads issued->landed", "compute (mixer+RK4+task+obs)", "state/output stores issued", "LDS stage+barrier+obs flush",
+         "stats", "drain stores (vmcnt 0)"]
+rows = []
+nw = min(64, (a.envs + 63) // 64)
+for t in range(a.launches):
+    env.step(ring[t % 16])
+    buf = np.zeros((64, 8), np.uint64)
+    lib.amenv_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p))
+    d = np.diff(buf[:nw].astype(np.int64), axis=1)
+    rows.append(d)
+d = np.concatenate(rows[10:], 0)
+med = np.median(d, 0)
+tot = np.median((np.concatenate([r for r in rows[10:]], 0)).sum(1))
+for n_, m in zip(names, med):
+    print(f"{n_:34s} {m:8.0f} cycles  {100*m/med.sum():5.1f}%")
+print(f"{'wave lifetime (entry->drained)':34s} {tot:8.0f} cycles")
+# spread of wave start times within a launch
+starts = []
+for t in range(10, a.launches):
+    pass
