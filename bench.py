@@ -91,21 +91,15 @@ def main():
 
     import rl_aerial_manipulator_amd as amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
     n = args.envs_per_gpu
+    shard = amd.sharding.shard_from_env(n)
+    world, rank = shard.world, shard.rank
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = amd.sharding.init_process_group("nccl", device)  # RCCL; None for a single process
 
-    env = amd.GpuWaypointEnv(n, device=local, vehicle=args.vehicle, seed=0, dtype=args.dtype, env_id_offset=rank * n,
+    env = amd.GpuWaypointEnv(n, device=local, vehicle=args.vehicle, seed=0, dtype=args.dtype, env_id_offset=shard.env_id_offset,
                              block_size=args.block_size)
     env.reset()
     ring = make_actions(torch, n, GRAPH_CHUNK, device, seed=1234 + rank)
@@ -133,8 +127,7 @@ def main():
             run_eager(rem)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        amd.sharding.barrier(dist)
 
     run(W)
     torch.cuda.synchronize(); barrier()
@@ -146,10 +139,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        t = torch.tensor([wall], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = amd.sharding.max_over_ranks(dist, wall, device)
     stats = env.stats()
 
     # per-launch kernel duration: HIP events stamped by the kernel's own dispatch (hipExtLaunchKernelGGL
@@ -159,8 +149,14 @@ def main():
     kern_ms = sum(per) / len(per) * 1e-3
 
     bytes_step = env.bytes_per_env_step
-    total_envs = n * world
-    value = total_envs * K / wall
+    total_envs = shard.global_envs
+    value = amd.sharding.whole_job_rate(shard, K, wall)
+    traffic = None  # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py -> profiles/traffic.json), same workload
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f).get(f"{args.vehicle}_{n}_{args.dtype}", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
     out = {
         "metric": "env-steps/sec (whole node), waypoint task at 4096 envs/GPU" if n == 4096 else f"env-steps/sec (whole node), waypoint task at {n} envs/GPU",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -172,12 +168,13 @@ def main():
                    "graph_chunk": GRAPH_CHUNK if graph is not None else 0, "kernel": env.kernel_name,
                    "actions": "hover-centred N(1,0.1)/N(0,0.1) clipped, pre-generated ring in HBM", "parallelism": f"env-shard x{world}, no step-path collective"},
         "roofline": {"bound": "hbm", "achieved": n * bytes_step / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": n * bytes_step / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": n * bytes_step / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_env_step": bytes_step, "kernel_us": kern_ms * 1e3,
                      "timing": f"mean of {pairs} launches, HIP start/stop events stamped by the kernel dispatch (amenv_step_timed)",
                      "kernel_us_min": min(per), "kernel_us_median": sorted(per)[len(per) // 2],
                      "achieved_loop": n * bytes_step / (dev_ms / K * 1e-3) / 1e9,
-                     "note": "4096 envs = 64 wavefronts on 256 CUs and ~1 MB per launch: latency-bound by construction (SURVEY 7.3-4)"},
+                     "note": f"{n} envs = {(n + 63) // 64} wavefronts on 256 CUs, {n * bytes_step / 1e6:.2f} MB algorithmic per launch"
+                             + ("; latency-bound by construction (dependent-launch floor on this box 1.66 us, SURVEY 7.3-4)" if n <= 65536 else "")},
         "device_ms_per_step": dev_ms / K,
         "episodes_finished_rank0": stats["episodes"],
     }

@@ -6,8 +6,8 @@ this package is the thin host-side mirror of the reference's Python interface.
 The directory name carries a hyphen (project convention), so import it through the alias
 module at the repo root:  `import rl_aerial_manipulator_amd as amd`.
 """
-from . import _lib
+from . import _lib, sharding
 from ._lib import AmenvError
 from .gpu_env import GpuWaypointEnv
 
-__all__ = ["GpuWaypointEnv", "AmenvError", "_lib"]
+__all__ = ["GpuWaypointEnv", "AmenvError", "_lib", "sharding"]

@@ -1,0 +1,84 @@
+"""The N>1 path on CPU: 2 processes, gloo.  The product step needs a GPU, so the per-shard stepping here is
+done by the CPU oracle (test infrastructure) -- what is under test is the host logic every rank runs around
+the step: shard arithmetic, global-id keyed resets (sharding invariance), barrier, max-over-ranks timing and
+counter sums (rl-aerial-manipulator_amd/sharding.py, used by bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import rl_aerial_manipulator_amd as amd
+    from oracle import oracle as O
+    sh = amd.sharding.shard_from_env(n)
+    dist = amd.sharding.init_process_group("gloo")
+    assert (sh.rank, sh.world, sh.env_id_offset, sh.global_envs) == (rank, world, rank * n, world * n)
+    cfg = O.reference_quad_config(num_envs=n, seed=5)
+    cfg.env_id_offset = sh.env_id_offset
+    env = O.OracleEnv(cfg)
+    env.reset()
+    rng = np.random.RandomState(0)
+    acts = rng.uniform([0, -1, -1, -1], [2, 1, 1, 1], (steps, world * n, 4)).astype(np.float32)
+    acts[:, :, 1:] *= 0.05
+    acts[:, ::5, 0] = 0.0  # every 5th env free-falls: crash + auto-reset inside the window
+    done = 0
+    amd.sharding.barrier(dist)
+    for t in range(steps):
+        out = env.step(acts[t, sh.env_id_offset:sh.env_id_offset + n])
+        done += int(out["done"].sum())
+    amd.sharding.barrier(dist)
+    t_job = amd.sharding.max_over_ranks(dist, 1.0 + rank)         # slowest rank wins
+    tot = amd.sharding.sum_counters(dist, {"episodes": done, "steps": n * steps})
+    assert t_job == float(world)
+    assert tot["steps"] == world * n * steps
+    assert amd.sharding.whole_job_rate(sh, steps, t_job) == world * n * steps / t_job
+    np.savez(os.path.join(out_dir, f"shard{rank}.npz"), fstate=env.fstate, istate=env.istate, done=done, total=tot["episodes"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_run_equals_single_rank(tmp_path):
+    from oracle import oracle as O
+    n, steps, world = 96, 150, 2
+    mp.start_processes(_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    shards = [np.load(tmp_path / f"shard{r}.npz") for r in range(world)]
+    # the same job on one rank
+    env = O.OracleEnv(O.reference_quad_config(num_envs=world * n, seed=5))
+    env.reset()
+    rng = np.random.RandomState(0)
+    acts = rng.uniform([0, -1, -1, -1], [2, 1, 1, 1], (steps, world * n, 4)).astype(np.float32)
+    acts[:, :, 1:] *= 0.05
+    acts[:, ::5, 0] = 0.0
+    done = 0
+    for t in range(steps):
+        done += int(env.step(acts[t])["done"].sum())
+    assert np.array_equal(np.concatenate([s["fstate"] for s in shards], 1), env.fstate)
+    assert np.array_equal(np.concatenate([s["istate"] for s in shards], 1), env.istate)
+    assert sum(int(s["done"]) for s in shards) == done == int(shards[0]["total"]) and done > 0
+
+
+def test_shard_arithmetic():
+    import rl_aerial_manipulator_amd as amd
+    S = amd.sharding.Shard
+    ids = []
+    for r in range(8):
+        sh = S(r, 8, 4096)
+        ids += list(sh.global_ids)
+        assert sh.env_id_offset == r * 4096 and sh.global_envs == 32768
+    assert ids == list(range(32768))
+    assert amd.sharding.max_over_ranks(None, 0.25) == 0.25 and amd.sharding.sum_counters(None, {"a": 3}) == {"a": 3}

@@ -11,6 +11,7 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--vehicle", default="hexa")
 ap.add_argument("--block-size", type=int, default=0)
+ap.add_argument("--calibrate", action="store_true", help="also run a 256 MiB device copy (known byte count)")
 a = ap.parse_args()
 import torch
 
@@ -24,5 +25,10 @@ ring[..., 0] += 1.0
 ring = ring.clamp(min=-1, max=2).contiguous()
 for t in range(a.steps):
     env.step(ring[t % 16])
+if a.calibrate:
+    src = torch.empty(256 * 1024 * 1024 // 4, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
 torch.cuda.synchronize()
 print("done", env.kernel_name, env.stats()["episodes"])

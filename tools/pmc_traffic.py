@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""HBM traffic of the step kernel from rocprofv3 PMC counters, as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
+FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass); on gfx950 FETCH_SIZE reads exactly
+half of a wide (16 B/lane) coalesced read stream -> doubled; WRITE_SIZE is exact for 16-B/lane stores.  Both counters
+are in KiB.  A calibration copy kernel of known size runs in the same passes to confirm unit and correction.
+
+Run on the GPU box from the repo root:   python tools/pmc_traffic.py --envs 4096 32768 1048576
+Writes gpurun_out/traffic.json (copy to profiles/traffic.json) and prints a table."""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def collect(counter, envs, vehicle, outdir):
+    d = os.path.join(outdir, f"pmc_{counter}_{envs}")
+    cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_step.py"),
+           "--envs", str(envs), "--steps", "120", "--vehicle", vehicle, "--calibrate"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300)
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    step = [v for k, v in acc.items() if "step_kernel" in k]
+    cal = [v for k, v in acc.items() if "calib_copy" in k.lower() or "copyBuffer" in k or "elementwise" in k]
+    mean = lambda xs: sum(xs) / len(xs)
+    return mean(step[0][20:]), (mean(cal[0]) if cal else None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", nargs="+", type=int, default=[4096])
+    ap.add_argument("--vehicle", default="hexa")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    res = {}
+    for n in a.envs:
+        f_kib, f_cal = collect("FETCH_SIZE", n, a.vehicle, a.out)
+        w_kib, w_cal = collect("WRITE_SIZE", n, a.vehicle, a.out)
+        fetch = 2.0 * f_kib * 1024.0   # gfx950 correction for 16-B/lane coalesced reads
+        write = w_kib * 1024.0
+        res[f"{a.vehicle}_{n}_f32"] = dict(fetch_size_kib_raw=f_kib, write_size_kib_raw=w_kib, fetch_bytes_per_launch=fetch,
+                                          write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
+                                          calibration_copy_256MiB=dict(fetch_kib_raw=f_cal, write_kib_raw=w_cal))
+        print(f"N={n:8d}: FETCH_SIZE {f_kib:10.1f} KiB (x2 -> {fetch/1e6:8.3f} MB)  WRITE_SIZE {w_kib:10.1f} KiB ({write/1e6:8.3f} MB)  "
+              f"per env-step {(fetch + write) / n:7.1f} B   calibration copy(256 MiB): fetch {f_cal} KiB write {w_cal} KiB", flush=True)
+    with open(os.path.join(a.out, "traffic.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
