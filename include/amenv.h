@@ -182,6 +182,11 @@ int amenv_destroy(amenv* env);
 /* Text of the last error on this handle (env may be NULL: last create error). */
 const char* amenv_last_error(const amenv* env);
 
+/* Re-key the reset RNG: episodes started after this call draw from (seed, global env id, episode).
+ * Replaces the role of `np.random.seed(k)` in front of the reference env (its reset(seed=) is a no-op,
+ * rl_env_scaledObs.py:41). */
+int amenv_set_seed(amenv* env, uint64_t seed);
+
 /* ---- the hot path ----------------------------------------------------------------- */
 
 /* Replaces WaypointQuadEnv.reset (rl_env_scaledObs.py:40-79) for every env whose mask

@@ -8,6 +8,8 @@ module at the repo root:  `import rl_aerial_manipulator_amd as amd`.
 """
 from . import _lib, sharding
 from ._lib import AmenvError
+from . import vec_env
 from .gpu_env import GpuWaypointEnv
+from .vec_env import GpuVecEnv
 
-__all__ = ["GpuWaypointEnv", "AmenvError", "_lib", "sharding"]
+__all__ = ["GpuWaypointEnv", "GpuVecEnv", "vec_env", "AmenvError", "_lib", "sharding"]

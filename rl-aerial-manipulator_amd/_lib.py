@@ -66,6 +66,7 @@ SYMBOLS = {
     "amenv_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(_P)]),
     "amenv_destroy": (C.c_int, [_P]),
     "amenv_last_error": (C.c_char_p, [_P]),
+    "amenv_set_seed": (C.c_int, [_P, C.c_uint64]),
     "amenv_reset": (C.c_int, [_P, _P, _P, _P]),
     "amenv_step": (C.c_int, [_P] * 10),
     "amenv_step_timed": (C.c_int, [_P] * 10 + [C.POINTER(C.c_float)]),

@@ -1,0 +1,179 @@
+"""rl_env_scaledObs -- single-environment facade with the reference's module and class names.
+
+`from rl_env_scaledObs import WaypointQuadEnv` (v2/rl_train.py:4, v2/runsim_scaledObs.py) resolves to this file when
+`rl-aerial-manipulator_amd/compat/` is on PYTHONPATH; the reference scripts then run textually unchanged while the
+physics, reward and state machine execute in the HIP kernels (N = 1 here: the compatibility path, not the fast path --
+use GpuVecEnv / GpuWaypointEnv for throughput).
+
+Mirrors v2/rl_env_scaledObs.py:9-231:
+  reset(seed=None) -> (obs f32[20], {})            :40-79
+  step(action)     -> (obs, reward, terminated, truncated, info)   :123-196   (raw env: NO auto-reset)
+  attributes read by the visualiser (v2/runsim_scaledObs.py:29,65-68,90; v2/simul_files/quadPlot.py:299-326):
+  quadcopter (.state, .position(), .velocity(), .omega(), .attitude(), .world_frame()), waypoint_list,
+  current_waypoint, waypoint_index, final_yaw, F, M, dt, counter, current_step, max_episode_steps.
+Deviation: the reference ignores `seed` (it draws from the global np.random, :41-52); here reset(seed=s) re-keys the
+counter-based reset RNG, reset() continues the stream.  The env does not print.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+try:
+    import gymnasium as _gym
+    _Base = _gym.Env
+except Exception:  # noqa: BLE001 - gymnasium is optional
+    _gym, _Base = None, object
+
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_amd = importlib.import_module("rl_aerial_manipulator_amd")
+_L = _amd._lib
+
+ARM_LENGTH, HEIGHT = 0.086, 0.05  # v2/simul_files/model/params.py:17-18 (world_frame geometry only)
+
+
+class _QuadcopterView:
+    """Read-only view with the accessor names of v2/simul_files/model/quadcopter.py:40-64."""
+
+    def __init__(self, env):
+        self._env = env
+
+    @property
+    def state(self):
+        return self._env._state13()
+
+    def position(self):
+        return self.state[0:3]
+
+    def velocity(self):
+        return self.state[3:6]
+
+    def omega(self):
+        return self.state[10:13]
+
+    def _rot(self):
+        # rotation matrix of the normalised quaternion (what Quaternion.as_rotation_matrix returns, utils/quaternion.py:60-77)
+        w, x, y, z = self.state[6:10] / np.linalg.norm(self.state[6:10])
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def attitude(self):
+        R = self._rot()  # utils/utils.py:11-15 RotToRPY
+        phi = np.arcsin(R[1, 2])
+        theta = np.arctan2(-R[0, 2] / np.cos(phi), R[2, 2] / np.cos(phi))
+        psi = np.arctan2(-R[1, 0] / np.cos(phi), R[1, 1] / np.cos(phi))
+        return phi, theta, psi
+
+    def world_frame(self):
+        """3x6: motor 1..4, origin, top marker in the world frame (quadcopter.py:40-51)."""
+        L, H = ARM_LENGTH, HEIGHT
+        body = np.array([[L, 0, 0], [0, L, 0], [-L, 0, 0], [0, -L, 0], [0, 0, 0], [0, 0, H]]).T
+        return self._rot() @ body + self.state[0:3, None]
+
+
+class WaypointQuadEnv(_Base):
+    def __init__(self, device=0, seed=0, backend=None, **env_kwargs):
+        if _Base is not object:
+            super().__init__()
+        from importlib import import_module
+        spaces = import_module("rl_aerial_manipulator_amd").vec_env.make_spaces()
+        self.observation_space, self.action_space = spaces
+        self._seed = seed
+        self._kw = dict(env_kwargs)
+        self._device = device
+        self._b = backend if backend is not None else _amd.GpuWaypointEnv(1, device=device, seed=seed, auto_reset=False, **self._kw)
+        self.dt = 1.0 / 200.0
+        self.max_episode_steps = int(self._b.cfg.task.max_episode_steps)
+        self.counter_limit = int(self._b.cfg.task.counter_limit)
+        self.quadcopter = None
+        self.F = None
+        self.M = None
+        self._cache = None
+
+    # ---- state readback (N = 1) ------------------------------------------------------------------
+    def _blob(self):
+        if self._cache is None:
+            f, i = self._b.get_state()
+            f = f.detach().cpu().numpy().astype(np.float64) if hasattr(f, "detach") else np.asarray(f, np.float64)
+            i = i.detach().cpu().numpy() if hasattr(i, "detach") else np.asarray(i)
+            self._cache = (f[:, 0].copy(), i[:, 0].copy())
+        return self._cache
+
+    def _state13(self):
+        return self._blob()[0][0:13]
+
+    @property
+    def waypoint_list(self):
+        f = self._blob()[0]
+        K = int(self._b.cfg.task.num_waypoints)
+        return [f[_L.F_WP0 + 3 * k:_L.F_WP0 + 3 * k + 3].copy() for k in range(K)]
+
+    @property
+    def waypoint_index(self):
+        return int(self._blob()[1][_L.I_FLAGS]) & 255
+
+    @property
+    def current_waypoint(self):
+        wl = self.waypoint_list
+        return wl[min(self.waypoint_index, len(wl) - 1)]
+
+    @property
+    def final_yaw(self):
+        return float(self._blob()[0][_L.F_FINAL_YAW])
+
+    @property
+    def last_distance(self):
+        d = float(self._blob()[0][_L.F_LAST_DISTANCE])
+        return None if d < 0 else d
+
+    @property
+    def final_waypoint_reached(self):
+        return bool(int(self._blob()[1][_L.I_FLAGS]) & _L.FLAGBIT_FWR)
+
+    @property
+    def counter_activated(self):
+        return bool(int(self._blob()[1][_L.I_FLAGS]) & _L.FLAGBIT_COUNTER_ACTIVE)
+
+    @property
+    def counter(self):
+        return int(self._blob()[1][_L.I_COUNTER])
+
+    @property
+    def current_step(self):
+        return int(self._blob()[1][_L.I_STEP])
+
+    # ---- gym API ------------------------------------------------------------------------------------
+    def reset(self, seed=None, options=None):
+        if seed is not None and hasattr(self._b, "reseed"):
+            self._b.reseed(int(seed))
+        obs = self._b.reset()
+        self._cache = None
+        self.quadcopter = _QuadcopterView(self)
+        obs = obs.detach().cpu().numpy() if hasattr(obs, "detach") else np.asarray(obs)
+        return obs[0].astype(np.float32).copy(), {}
+
+    def step(self, action):
+        import torch
+        a = np.asarray(action, dtype=np.float32).reshape(4)
+        v = self._b.cfg.vehicle
+        # telemetry exactly as the reference computes it (float32 products, rl_env_scaledObs.py:125-128)
+        self.F = (a[0] * np.float32(v.mass)) * np.float32(v.g)
+        self.M = a[1:4] * np.float32(v.moment_scale)
+        obs, rew, done, bits = self._b.step(torch.from_numpy(a.reshape(1, 4)))
+        self._cache = None
+        to_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+        b = int(to_np(bits).view(np.uint32)[0])
+        info = importlib.import_module("rl_aerial_manipulator_amd").vec_env.info_dict(b)
+        return (to_np(obs)[0].astype(np.float32).copy(), float(to_np(rew)[0]), bool(b & _L.INFO_TERMINATED), bool(b & _L.INFO_TRUNCATED), info)
+
+    def _get_observation(self):
+        o = self._b.observe()
+        return (o.detach().cpu().numpy() if hasattr(o, "detach") else np.asarray(o))[0].astype(np.float32)
+
+    def close(self):
+        if hasattr(self._b, "close"):
+            self._b.close()

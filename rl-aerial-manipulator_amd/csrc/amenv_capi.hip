@@ -364,6 +364,12 @@ int amenv_destroy(amenv* e) {
 const char* amenv_last_error(const amenv* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 const char* amenv_kernel_name(const amenv* e) { return e ? e->kname.c_str() : ""; }
 
+int amenv_set_seed(amenv* e, uint64_t seed) {
+  if (!e) return AMENV_ERR_INVALID;
+  e->cfg.seed = seed;
+  return AMENV_OK;
+}
+
 int amenv_reset(amenv* e, const uint8_t* mask, float* obs_out, void* stream) {
   if (!e) return AMENV_ERR_INVALID;
   DeviceGuard g(e->device);

@@ -93,6 +93,11 @@ class GpuWaypointEnv:
             actions = actions.to(device=self.device, dtype=torch.float32).reshape(want).contiguous()
         return actions
 
+    def reseed(self, seed):
+        """Re-key the reset RNG for episodes started from now on."""
+        self._check(self.lib.amenv_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF), "amenv_set_seed")
+        self.cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
     def reset(self, mask=None):
         """WaypointQuadEnv.reset (v2/rl_env_scaledObs.py:40-79) for all envs, or those with mask != 0."""
         m = None
