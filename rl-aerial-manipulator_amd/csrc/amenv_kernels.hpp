@@ -183,22 +183,28 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   observe<T, KW>(K, e, o);
   was_reset = false;
   ep_len_out = 0; ep_ret_out = 0.0f;
-  if (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) {  // SB3 DummyVecEnv + Monitor contract
-    ep_len_out = e.step; ep_ret_out = float(e.ep_return);
-    if (active) {
-      if (io.terminal_obs) {
-        float4* t = reinterpret_cast<float4*>(io.terminal_obs + size_t(i) * kObsDim);
+  const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+  const bool resets = ended && (P.flags & AMENV_FLAG_AUTO_RESET);
+  if (__ballot(ended) != 0ull) {  // wave-uniform: the whole cold path is skipped by waves with no episode end
+    uint32_t r[12];
+    reset_words_wave(C, resets, C.gid0 + i, e.episode, r);  // all lanes take part, lanes 0..2 do the work
+    if (ended) {  // SB3 DummyVecEnv + Monitor contract
+      ep_len_out = e.step; ep_ret_out = float(e.ep_return);
+      if (active) {
+        if (io.terminal_obs) {
+          float4* t = reinterpret_cast<float4*>(io.terminal_obs + size_t(i) * kObsDim);
 #pragma unroll
-        for (int j = 0; j < 5; j++) t[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+          for (int j = 0; j < 5; j++) t[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+        }
+        if (io.ep_return) io.ep_return[i] = ep_ret_out;
+        if (io.ep_len) io.ep_len[i] = ep_len_out;
       }
-      if (io.ep_return) io.ep_return[i] = ep_ret_out;
-      if (io.ep_len) io.ep_len[i] = ep_len_out;
-    }
-    if (P.flags & AMENV_FLAG_AUTO_RESET) {
-      reset_env<T, KW>(C, K, e, C.gid0 + i);
-      observe<T, KW>(K, e, o);
-      bits |= AMENV_INFO_WAS_RESET;
-      was_reset = true;
+      if (resets) {
+        reset_from_words<T, KW>(C, K, e, r);
+        observe<T, KW>(K, e, o);
+        bits |= AMENV_INFO_WAS_RESET;
+        was_reset = true;
+      }
     }
   }
   return bits;
@@ -265,11 +271,20 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
     io.info[i] = bits;
   }
   AMENV_STAMP(4);          // state/outputs stores issued
+#ifdef AMENV_DIAG_DIRECT_OBS
+  if (active) {
+    float4* d = reinterpret_cast<float4*>(io.obs + size_t(i) * kObsDim);
+#pragma unroll
+    for (int j = 0; j < 5; j++) d[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+  }
+  (void)lds;
+#else
   stage_obs(lds + threadIdx.x * kObsDim, o);
   __syncthreads();
   const int row0 = blockIdx.x * BS;
   const int rows = min(BS, hd.n - row0);
   flush_obs(lds, io.obs + size_t(row0) * kObsDim, rows);
+#endif
   AMENV_STAMP(5);          // obs flushed
   AMENV_STAMP(6);
 #ifdef AMENV_STAMPS

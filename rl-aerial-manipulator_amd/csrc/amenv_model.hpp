@@ -63,9 +63,33 @@ __device__ __forceinline__ float rsqrt_(float x) {                              
   return y * __builtin_fmaf(-0.5f * x, y * y, 1.5f);
 }
 __device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
-__device__ __forceinline__ float atan2_(float a, float b) { return atan2f(a, b); }
+// fp32 atan2 / asin for the hold-phase bonuses (rl_env_scaledObs.py:163,169-171).  The device libm versions cost
+// ~430 cycles each for a lone wavefront and the hold phase is where a trained policy spends ~500 steps per episode,
+// so they are replaced by a compact form: octant reduction + the cephes atanf minimax polynomial on |t| <= tan(pi/8)
+// (abs error <= 3e-7 rad incl. the two v_rcp_f32; the bonuses scale angles by <= 50, far inside the 1e-5 gate).
+__device__ __forceinline__ float atan_reduced_(float t) {  // |t| <= 0.41421356
+  const float z = t * t;
+  float p = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+  p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+  return __builtin_fmaf(p * z, t, t);
+}
+__device__ __forceinline__ float atan2_(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const bool swap = ay > ax;
+  const float mx = swap ? ay : ax, mn = swap ? ax : ay;
+  const float t = mn * __builtin_amdgcn_rcpf(mx);                       // [0, 1]
+  const bool big = t > 0.41421356237f;
+  const float tr = big ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t;
+  float a = atan_reduced_(tr);
+  a = big ? a + 0.78539816339744831f : a;
+  a = swap ? 1.57079632679489662f - a : a;
+  a = x < 0.0f ? 3.14159265358979324f - a : a;
+  a = mx == 0.0f ? 0.0f : a;
+  return __builtin_copysignf(a, y);
+}
 __device__ __forceinline__ double atan2_(double a, double b) { return atan2(a, b); }
-__device__ __forceinline__ float asin_(float a) { return asinf(a); }
+__device__ __forceinline__ float asin_(float a) { return atan2_(a, __builtin_amdgcn_sqrtf((1.0f - a) * (1.0f + a))); }
 __device__ __forceinline__ double asin_(double a) { return asin(a); }
 __device__ __forceinline__ float clamp_(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }  // v_med3_f32
 __device__ __forceinline__ double clamp_(double x, double lo, double hi) { return __builtin_fmax(__builtin_fmin(x, hi), lo); }
@@ -247,24 +271,24 @@ __device__ __forceinline__ uint32_t task_step(const PT& P, Env<T, KW>& e, T& rew
       sp = sp > T(1) ? T(1) : (sp < T(-1) ? T(-1) : sp);
       const T pitch = asin_(sp);
       const T yaw = atan2_(T(2) * fma_(e.qw, e.qz, e.qx * e.qy), fma_(T(-2), fma_(e.qy, e.qy, e.qz * e.qz), T(1)));
-      const T two_pi = T(6.28318530717958647692);
+      // bonuses: divisions by constants as multiplications by the rounded reciprocal (<= 1 ulp), selects not branches
+      const T two_pi = T(6.28318530717958647692), inv_two_pi = T(0.15915494309189533577);
       const T dyaw = abs_(yaw - e.final_yaw);
+      const T yaw_f = dyaw < two_pi ? T(1) - dyaw * inv_two_pi : T(0);     // (1 - |dyaw|/2pi) or 0   :163,169
       bits |= AMENV_INFO_SUCCESS;
       if (vn < T(0.1) && wn < T(0.1)) bits |= AMENV_INFO_STOPPED;
-      if (!fwr) {                                                       // :156-164 first arrival
-        cact = true; fwr = true;
-        const T stop_b = vn < T(1) ? T(150) * (T(1) - v2) : T(0);
-        const T yaw_b = dyaw < two_pi ? T(100) * (T(1) - dyaw / two_pi) : T(0);
-        reward = ((reward + T(200)) + stop_b) + yaw_b;
-      } else {                                                          // :165-179 holding
-        const T yaw_b = dyaw < two_pi ? T(30) * (T(1) - dyaw / two_pi) : T(0);
-        const T ar = abs_(roll), ap = abs_(pitch);
-        const T roll_b = ar < T(0.2) ? T(10) * (T(1) - ar / T(0.2)) : T(-0.1) * ar;
-        const T pitch_b = ap < T(0.2) ? T(10) * (T(1) - ap / T(0.2)) : T(-0.1) * ap;
-        reward = ((reward + yaw_b) + roll_b) + pitch_b;
+      const T ar = abs_(roll), ap = abs_(pitch);
+      const T roll_b = ar < T(0.2) ? T(10) * (T(1) - ar * T(5)) : T(-0.1) * ar;      // :170,176
+      const T pitch_b = ap < T(0.2) ? T(10) * (T(1) - ap * T(5)) : T(-0.1) * ap;     // :171,177
+      const T stop_b = vn < T(1) ? T(150) * (T(1) - v2) : T(0);                      // :162
+      const T r_first = ((reward + T(200)) + stop_b) + T(100) * yaw_f;               // :164 first arrival
+      const T r_hold = ((reward + T(30) * yaw_f) + roll_b) + pitch_b;                // :173,179 holding
+      reward = fwr ? r_hold : r_first;
+      if (fwr) {                                                        // :165-179 holding
         if (e.counter <= P.counter_limit) e.counter += 1;               // :166-167
         else bits |= AMENV_INFO_TERMINATED;                             // :174-179
       }
+      cact = true; fwr = true;                                          // :157-158 (no-ops when already holding)
       returned = true;
     }
   }
@@ -301,12 +325,42 @@ __device__ __forceinline__ float u01(uint32_t r) { return float(r >> 8) * 5.9604
 
 // WaypointQuadEnv.reset (rl_env_scaledObs.py:40-79) with the DESIGN.md draw table.  All draws
 // are formed in fp32 with explicit fmaf so the CPU oracle reproduces them bit for bit.
-template <typename T, int KW>
-__device__ __forceinline__ void reset_env(const ColdParams& P, int K, Env<T, KW>& e, int64_t gid) {
-  uint32_t r[12];
+// The 12 Philox words of one reset, computed by the resetting lane itself (three blocks in sequence).
+__device__ __forceinline__ void reset_words_serial(const ColdParams& P, int64_t gid, int32_t episode, uint32_t* r) {
 #pragma unroll
   for (uint32_t b = 0; b < 3; b++)
-    philox4x32_10(P.seed_lo, P.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(e.episode), b, &r[4 * b]);
+    philox4x32_10(P.seed_lo, P.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(episode), b, &r[4 * b]);
+}
+
+// Same 12 words, wave-cooperative: episode ends are rare, so when a wave enters the reset path usually ONE lane
+// needs words while 63 idle.  For each resetting lane (scalar loop) lanes 0..2 each run one of the three Philox
+// blocks (block index = lane id) and the 12 results are handed to the owner through v_readlane: one block of
+// latency instead of three (the 32x32->64 multiplies are quarter rate).  Must be called by ALL lanes of the wave.
+__device__ __forceinline__ void reset_words_wave(const ColdParams& P, bool need, int64_t gid, int32_t episode, uint32_t* r) {
+  unsigned long long m = __ballot(need);
+  const int lane = int(threadIdx.x & 63);
+  const uint32_t g_lo = uint32_t(uint64_t(gid)), g_hi = uint32_t(uint64_t(gid) >> 32);
+  while (m) {  // wave-uniform
+    const int l = __builtin_ctzll(m);
+    m &= m - 1;
+    const uint32_t c0 = __builtin_amdgcn_readlane(g_lo, l), c1 = __builtin_amdgcn_readlane(g_hi, l);
+    const uint32_t c2 = uint32_t(__builtin_amdgcn_readlane(episode, l));
+    uint32_t w[4];
+    philox4x32_10(P.seed_lo, P.seed_hi, c0, c1, c2, uint32_t(lane), w);   // lanes 0,1,2 hold blocks 0,1,2
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t v = __builtin_amdgcn_readlane(w[k], b);
+        if (lane == l) r[4 * b + k] = v;
+      }
+  }
+}
+
+// WaypointQuadEnv.reset (rl_env_scaledObs.py:40-79) from its 12 Philox words r[] (DESIGN.md draw table).  All draws
+// are formed in fp32 with explicit fmaf so the CPU oracle reproduces them bit for bit.
+template <typename T, int KW>
+__device__ __forceinline__ void reset_from_words(const ColdParams& P, int K, Env<T, KW>& e, const uint32_t* r) {
   const float PIF = 3.14159274101257324f;
   const float sx = fmaf(2.0f, u01(r[0]), -1.0f);                        // :44
   const float sy = fmaf(2.0f, u01(r[1]), -1.0f);
@@ -346,6 +400,13 @@ __device__ __forceinline__ void reset_env(const ColdParams& P, int K, Env<T, KW>
   e.ep_return = T(0);
   e.step = 0; e.counter = 0; e.flags = 0;                               // :55-59,74-77
   e.episode += 1;
+}
+
+template <typename T, int KW>
+__device__ __forceinline__ void reset_env(const ColdParams& P, int K, Env<T, KW>& e, int64_t gid) {
+  uint32_t r[12];
+  reset_words_serial(P, gid, e.episode, r);
+  reset_from_words<T, KW>(P, K, e, r);
 }
 
 }  // namespace amenv_dev
