@@ -137,7 +137,8 @@ enum amenv_float_field {
 enum amenv_int_field {
   AMENV_I_STEP = 0,   /* current_step (:55)                                         */
   AMENV_I_COUNTER,    /* counter (:57)                                              */
-  AMENV_I_FLAGS,      /* bits 0-7 waypoint_index, bit 8 final_waypoint_reached, bit 9 counter_activated */
+  AMENV_I_FLAGS,      /* bits 0-3 waypoint_index, bits 4-7 waypoints of this episode (v1 tasks; 0 = num_waypoints),
+                         bit 8 final_waypoint_reached, bit 9 counter_activated */
   AMENV_I_EPISODE,    /* episodes started so far by this env (RNG counter)          */
   AMENV_I_NFIELDS
 };
@@ -163,6 +164,11 @@ typedef struct amenv amenv; /* opaque */
  * "quad" (reference, oracle-pinned) | "hexa" | "hexa_arm" (hexacopter_description/
  * and Manipulator/ SDF parameters; no reference dynamics => parity unpinned). */
 int amenv_default_config(const char* vehicle_name, int32_t num_envs, amenv_config* cfg);
+
+/* Select which reference env file the task follows and fill that file's literals:
+ * AMENV_TASK_V2_SCALED20 (v2/rl_env_scaledObs.py, 20-D obs, 2000 steps) or AMENV_TASK_V1_SCALED17 / _RAW17
+ * (v1/rl_env_scaledObs.py / v1/rl_env.py: 17-D obs, 1..2 waypoints per episode, 1200 steps; used by v1/rl_train_vecN.py). */
+int amenv_config_set_task(amenv_config* cfg, int32_t variant);
 
 /* obs_dim / act_dim / number of float state fields for a config. */
 int amenv_dims(const amenv_config* cfg, int32_t* obs_dim, int32_t* act_dim, int32_t* n_float_fields,

@@ -205,6 +205,7 @@ typedef struct {
   double wp[AMENV_MAX_WAYPOINTS][3];
   double final_yaw, last_distance, ep_return;
   int step, counter, wp_index, fwr, counter_activated, episode;
+  int k_env; /* v1: waypoints of THIS episode (v1/rl_env_scaledObs.py:38); 0 = cfg->task.num_waypoints */
 } env_t;
 
 static void load_env(const amenv_config* cfg, int n, const double* f, const int32_t* is, int i, env_t* e) {
@@ -217,7 +218,7 @@ static void load_env(const amenv_config* cfg, int n, const double* f, const int3
   e->step = is[(size_t)AMENV_I_STEP * n + i];
   e->counter = is[(size_t)AMENV_I_COUNTER * n + i];
   int fl = is[(size_t)AMENV_I_FLAGS * n + i];
-  e->wp_index = fl & 255; e->fwr = (fl & AMENV_FLAGBIT_FWR) != 0; e->counter_activated = (fl & AMENV_FLAGBIT_COUNTER_ACTIVE) != 0;
+  e->wp_index = fl & 15; e->k_env = (fl >> 4) & 15; e->fwr = (fl & AMENV_FLAGBIT_FWR) != 0; e->counter_activated = (fl & AMENV_FLAGBIT_COUNTER_ACTIVE) != 0;
   e->episode = is[(size_t)AMENV_I_EPISODE * n + i];
 }
 
@@ -230,12 +231,32 @@ static void store_env(const amenv_config* cfg, int n, double* f, int32_t* is, in
     for (int c = 0; c < 3; c++) f[(size_t)(AMENV_F_WP0 + 3 * k + c) * n + i] = e->wp[k][c];
   is[(size_t)AMENV_I_STEP * n + i] = e->step;
   is[(size_t)AMENV_I_COUNTER * n + i] = e->counter;
-  is[(size_t)AMENV_I_FLAGS * n + i] = (e->wp_index & 255) | (e->fwr ? AMENV_FLAGBIT_FWR : 0) | (e->counter_activated ? AMENV_FLAGBIT_COUNTER_ACTIVE : 0);
+  is[(size_t)AMENV_I_FLAGS * n + i] = (e->wp_index & 15) | ((e->k_env & 15) << 4) | (e->fwr ? AMENV_FLAGBIT_FWR : 0) | (e->counter_activated ? AMENV_FLAGBIT_COUNTER_ACTIVE : 0);
   is[(size_t)AMENV_I_EPISODE * n + i] = e->episode;
 }
 
+static int is_v1(const amenv_config* cfg) { return cfg->task.variant == AMENV_TASK_V1_SCALED17 || cfg->task.variant == AMENV_TASK_V1_RAW17; }
+static int obs_dim(const amenv_config* cfg) { return is_v1(cfg) ? 17 : 20; }
+int orc_obs_dim(const amenv_config* cfg) { return obs_dim(cfg); }
+static int env_K(const amenv_config* cfg, const env_t* e) { return e->k_env ? e->k_env : cfg->task.num_waypoints; }
+
+/* v1 _get_observation: v1/rl_env_scaledObs.py:65-83 (scaled) and v1/rl_env.py:65-83 (raw: pos, vel, omega, rel_pos unscaled) */
+static void observe_v1(const amenv_config* cfg, const env_t* e, float* obs) {
+  const int K = env_K(cfg, e);
+  const int idx = e->wp_index < K ? e->wp_index : K - 1;
+  const double* cw = e->wp[idx];
+  const int raw = cfg->task.variant == AMENV_TASK_V1_RAW17;
+  const double sp = raw ? 1.0 : 10.0, sv = raw ? 1.0 : 5.0, sr = raw ? 1.0 : 2.0;
+  for (int c = 0; c < 3; c++) obs[c] = (float)(e->s[c] / sp);              /* :75 */
+  for (int c = 0; c < 3; c++) obs[3 + c] = (float)(e->s[3 + c] / sv);      /* :76 */
+  for (int c = 0; c < 4; c++) obs[6 + c] = (float)(e->s[6 + c]);           /* :77 */
+  for (int c = 0; c < 3; c++) obs[10 + c] = (float)(e->s[10 + c] / sv);    /* :78 */
+  for (int c = 0; c < 3; c++) obs[13 + c] = (float)((cw[c] - e->s[c]) / sr); /* :71,79 */
+  obs[16] = idx >= K - 1 ? 1.0f : 0.0f;  /* :80 np.allclose(current_waypoint, waypoint_list[-1]) */
+}
+
 /* _get_observation, rl_env_scaledObs.py:98-121 */
-static void observe(const amenv_config* cfg, const env_t* e, float* obs) {
+static void observe_v2(const amenv_config* cfg, const env_t* e, float* obs) {
   const int K = cfg->task.num_waypoints;
   const int idx = e->wp_index < K ? e->wp_index : K - 1; /* current_waypoint stays at the last one (:151-152) */
   const double* cw = e->wp[idx];
@@ -250,6 +271,10 @@ static void observe(const amenv_config* cfg, const env_t* e, float* obs) {
     obs[16 + c] = (float)(rel / 2.0);
   }
   obs[19] = (float)(e->final_yaw / PI_D);                                  /* :118 */
+}
+
+static void observe(const amenv_config* cfg, const env_t* e, float* obs) {
+  if (is_v1(cfg)) observe_v1(cfg, e, obs); else observe_v2(cfg, e, obs);
 }
 
 /* quaternion_to_rpy, utils2/utils.py:4-9: scipy Rotation.from_quat([x,y,z,w]).as_euler('xyz'),
@@ -267,7 +292,7 @@ static double norm3(const double* a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a
 
 /* One WaypointQuadEnv.step, rl_env_scaledObs.py:123-196 (+ _calculate_reward :198-231).
  * Returns info bits; *reward_out the f64 reward.  No auto-reset here. */
-static uint32_t env_step(const amenv_config* cfg, env_t* e, const float* action, double* reward_out) {
+static uint32_t env_step_v2(const amenv_config* cfg, env_t* e, const float* action, double* reward_out) {
   const int K = cfg->task.num_waypoints;
   orc_dynamics_step(cfg, e->s, action, NULL);                              /* :125-131 */
 
@@ -355,6 +380,70 @@ static uint32_t env_step(const amenv_config* cfg, env_t* e, const float* action,
   return bits;
 }
 
+/* One v1 WaypointQuadEnv.step: v1/rl_env_scaledObs.py:85-140 (+ _calculate_reward :142-168); v1/rl_env.py is identical
+ * except for the observation scaling. */
+static uint32_t env_step_v1(const amenv_config* cfg, env_t* e, const float* action, double* reward_out) {
+  const int K = env_K(cfg, e);
+  orc_dynamics_step(cfg, e->s, action, NULL);                              /* :87-90 */
+  uint32_t bits = 0;
+  if (cfg->flags & AMENV_FLAG_NAN_GUARD) {
+    int bad = 0; for (int k = 0; k < 13; k++) bad |= !isfinite(e->s[k]);
+    if (bad) {
+      bits = AMENV_INFO_TERMINATED | AMENV_INFO_NONFINITE;
+      if (e->step >= cfg->task.max_episode_steps) bits |= AMENV_INFO_TRUNCATED;
+      e->step += 1; *reward_out = -100.0; return bits;
+    }
+  }
+  const double* pos = &e->s[0]; const double* vel = &e->s[3]; const double* om = &e->s[10];
+  const int idx0 = e->wp_index < K ? e->wp_index : K - 1;
+  const double* cw = e->wp[idx0];
+  /* _calculate_reward (:142-168) */
+  double dvec[3] = {pos[0] - cw[0], pos[1] - cw[1], pos[2] - cw[2]};
+  const double distance = norm3(dvec);                                     /* :148 */
+  const double distance_reward = -distance * 2;                            /* :151 */
+  const double vn = norm3(vel), wn = norm3(om);
+  double speed_penalty = -0.1 * (vn * vn);                                 /* :152 */
+  if (wn > 0.1) speed_penalty -= 0.01 * (wn * wn);                         /* :153-154 */
+  const double time_penalty = -0.1;                                        /* :155 */
+  double progress_reward;
+  if (e->last_distance >= 0.0) {                                           /* :158-164 */
+    progress_reward = 20 * (e->last_distance - distance);
+    if (progress_reward > 0) progress_reward += 2;
+  } else progress_reward = 0.0;
+  e->last_distance = distance;                                             /* :166 */
+  double reward = distance_reward + speed_penalty + time_penalty + progress_reward; /* :168 */
+  /* approach shaping (:102-110) */
+  const double dir[3] = {cw[0] - pos[0], cw[1] - pos[1], cw[2] - pos[2]};
+  const double dn = norm3(dir);
+  const double vtw = vel[0] * (dir[0] / dn) + vel[1] * (dir[1] / dn) + vel[2] * (dir[2] / dn);   /* :103-104 */
+  if (distance < 0.5 && vtw > 0.1) reward += 10.0;                         /* :107-108 */
+  else if (distance < 0.5 && vtw < 0.1) reward -= 10.0;                    /* :109-110 */
+  if (distance < 0.1) {                                                    /* :111 */
+    reward += 100.0; e->wp_index += 1;                                     /* :112-113 */
+    if (!(e->wp_index < K)) {                                              /* :117-124: all waypoints reached */
+      const double rot_b = wn < 0.1 ? 100.0 : -20.0 * wn;                  /* :122 */
+      const double stop_b = vn < 0.1 ? 100.0 : -10.0 * vn;                 /* :123 */
+      *reward_out = reward + 400.0 + stop_b + rot_b;                       /* :124: returns BEFORE current_step += 1, truncated = False */
+      return AMENV_INFO_TERMINATED | AMENV_INFO_SUCCESS | (vn < 0.1 ? AMENV_INFO_STOPPED : 0);
+    }
+  }
+  const int truncated = e->step >= cfg->task.max_episode_steps;            /* :126 */
+  e->step += 1;                                                            /* :127 */
+  if (truncated) bits |= AMENV_INFO_TRUNCATED;
+  if (pos[2] < 0.1) {                                                      /* :131-136 */
+    reward -= 100;
+    if (vel[2] < 0) reward += vel[2] * 100.0;
+    *reward_out = reward;
+    return bits | AMENV_INFO_TERMINATED | AMENV_INFO_CRASHED;
+  }
+  if (norm3(pos) > 10) {                                                   /* :137-139 */
+    reward -= 100.0; *reward_out = reward;
+    return bits | AMENV_INFO_TERMINATED | AMENV_INFO_OOB;
+  }
+  *reward_out = reward;                                                    /* :140 */
+  return bits;
+}
+
 /* ------------------------------------------------------------------------------------
  * reset: rl_env_scaledObs.py:40-79 + utils2/utils.py:12-95, with the DESIGN.md Philox spec
  * in place of global np.random.  All draws are formed in fp32 (the product dtype) and widened.
@@ -379,7 +468,37 @@ void orc_philox(uint64_t seed, uint64_t gid, uint32_t episode, uint32_t block, u
 
 static float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; } /* [0,1), 24 bits, exact */
 
+static uint32_t env_step(const amenv_config* cfg, env_t* e, const float* action, double* reward_out) {
+  return is_v1(cfg) ? env_step_v1(cfg, e, action, reward_out) : env_step_v2(cfg, e, action, reward_out);
+}
+
+
+/* v1 reset: v1/rl_env_scaledObs.py:32-63.  Draw table: start = (2u0-1, 2u1-1, 1+u3); K = 1 + (r2 >> 31);
+ * waypoint k = (2u(4+3k)-1, 2u(5+3k)-1, 1+2u(6+3k)), k = 0..K-1 (capped by cfg num_waypoints, the storage bound). */
+static void env_reset_v1(const amenv_config* cfg, int64_t gid, env_t* e) {
+  uint32_t r[12];
+  for (uint32_t b = 0; b < 3; b++) orc_philox(cfg->seed, (uint64_t)gid, (uint32_t)e->episode, b, &r[4 * b]);
+  int K = 1 + (int)(r[2] >> 31);                                   /* :38 randint(1,3) */
+  if (K > cfg->task.num_waypoints) K = cfg->task.num_waypoints;
+  memset(e->s, 0, sizeof(e->s));
+  e->s[0] = fmaf(2.0f, u01(r[0]), -1.0f); e->s[1] = fmaf(2.0f, u01(r[1]), -1.0f);  /* :36 */
+  e->s[2] = fmaf(1.0f, u01(r[3]), 1.0f);                           /* :37 */
+  e->s[6] = 1.0;                                                   /* :40 attitude (0,0,0) */
+  for (int k = 0; k < AMENV_MAX_WAYPOINTS; k++) for (int c = 0; c < 3; c++) e->wp[k][c] = 0.0;
+  for (int k = 0; k < K; k++) {                                    /* :53-63 */
+    e->wp[k][0] = fmaf(2.0f, u01(r[4 + 3 * k]), -1.0f);
+    e->wp[k][1] = fmaf(2.0f, u01(r[5 + 3 * k]), -1.0f);
+    e->wp[k][2] = fmaf(2.0f, u01(r[6 + 3 * k]), 1.0f);
+  }
+  e->k_env = K;
+  e->final_yaw = 0.0; e->last_distance = -1.0; e->ep_return = 0.0;
+  e->step = 0; e->counter = 0; e->wp_index = 0; e->fwr = 0; e->counter_activated = 0;
+  e->episode += 1;
+}
+
 static void env_reset(const amenv_config* cfg, int64_t gid, env_t* e) {
+  if (is_v1(cfg)) { env_reset_v1(cfg, gid, e); return; }
+  e->k_env = 0;
   const int K = cfg->task.num_waypoints;
   uint32_t r[12];
   for (uint32_t b = 0; b < 3; b++) orc_philox(cfg->seed, (uint64_t)gid, (uint32_t)e->episode, b, &r[4 * b]);
@@ -428,7 +547,7 @@ static void env_reset(const amenv_config* cfg, int64_t gid, env_t* e) {
  * ---------------------------------------------------------------------------------- */
 int orc_reset(const amenv_config* cfg, double* fstate, int32_t* istate, const uint8_t* mask, float* obs_out) {
   const int n = cfg->num_envs;
-  const int od = 20;
+  const int od = obs_dim(cfg);
   for (int i = 0; i < n; i++) {
     env_t e; load_env(cfg, n, fstate, istate, i, &e);
     if (!mask || mask[i]) { env_reset(cfg, cfg->env_id_offset + i, &e); store_env(cfg, n, fstate, istate, i, &e); }
@@ -439,7 +558,7 @@ int orc_reset(const amenv_config* cfg, double* fstate, int32_t* istate, const ui
 
 int orc_observe(const amenv_config* cfg, const double* fstate, const int32_t* istate, float* obs_out) {
   const int n = cfg->num_envs;
-  for (int i = 0; i < n; i++) { env_t e; load_env(cfg, n, fstate, istate, i, &e); observe(cfg, &e, obs_out + (size_t)i * 20); }
+  for (int i = 0; i < n; i++) { env_t e; load_env(cfg, n, fstate, istate, i, &e); observe(cfg, &e, obs_out + (size_t)i * obs_dim(cfg)); }
   return 0;
 }
 
@@ -448,7 +567,7 @@ int orc_observe(const amenv_config* cfg, const double* fstate, const int32_t* is
 int orc_step(const amenv_config* cfg, double* fstate, int32_t* istate, const float* actions, float* obs, double* reward,
              uint8_t* done, uint32_t* info_bits, float* terminal_obs, float* ep_return, int32_t* ep_len, int nthreads) {
   const int n = cfg->num_envs;
-  const int od = 20, ad = 4;
+  const int od = obs_dim(cfg), ad = 4;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(static) if (nthreads != 1)

@@ -21,6 +21,7 @@ F32, F64 = 0, 1
 F_FINAL_YAW, F_LAST_DISTANCE, F_EP_RETURN, F_WP0 = 13, 14, 15, 16
 I_STEP, I_COUNTER, I_FLAGS, I_EPISODE, I_NFIELDS = 0, 1, 2, 3, 4
 FLAGBIT_FWR, FLAGBIT_COUNTER_ACTIVE = 256, 512
+TASK_V2_SCALED20, TASK_V1_SCALED17, TASK_V1_RAW17 = 0, 1, 2
 
 
 class Vehicle(C.Structure):
@@ -74,6 +75,7 @@ def lib():
         L.orc_reference_quad.argtypes = [C.POINTER(Config), C.c_int32]
         L.orc_set_num_waypoints.argtypes = [C.POINTER(Config), C.c_int32]
         L.orc_n_float_fields.argtypes = [C.POINTER(Config)]
+        L.orc_obs_dim.argtypes = [C.POINTER(Config)]
         L.orc_dynamics_step.argtypes = [C.POINTER(Config), P, P, P]
         L.orc_reset.argtypes = [C.POINTER(Config), P, P, P, P]
         L.orc_observe.argtypes = [C.POINTER(Config), P, P, P]
@@ -89,12 +91,16 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def reference_quad_config(num_envs=1, seed=0, flags=FLAG_AUTO_RESET, num_waypoints=1):
+def reference_quad_config(num_envs=1, seed=0, flags=FLAG_AUTO_RESET, num_waypoints=1, variant=TASK_V2_SCALED20):
     cfg = Config()
     lib().orc_reference_quad(C.byref(cfg), num_envs)
     cfg.seed = seed
     cfg.flags = flags
-    if num_waypoints != 1:
+    if variant != TASK_V2_SCALED20:        # v1 envs: 17-D obs, 1..2 waypoints per episode, 1200-step limit
+        cfg.task.variant = variant
+        cfg.task.num_waypoints = 2         # v1/rl_env_scaledObs.py:38 (storage bound; per-episode K is drawn at reset)
+        cfg.task.max_episode_steps = 1200  # v1/rl_env_scaledObs.py:43
+    elif num_waypoints != 1:
         lib().orc_set_num_waypoints(C.byref(cfg), num_waypoints)
     return cfg
 
@@ -108,7 +114,7 @@ class OracleEnv:
         self.nf = lib().orc_n_float_fields(C.byref(cfg))
         self.fstate = np.zeros((self.nf, self.n), np.float64)
         self.istate = np.zeros((I_NFIELDS, self.n), np.int32)
-        self.obs_dim, self.act_dim = 20, 4
+        self.obs_dim, self.act_dim = lib().orc_obs_dim(C.byref(cfg)), 4
 
     def reset(self, mask=None):
         obs = np.zeros((self.n, self.obs_dim), np.float32)
@@ -143,7 +149,7 @@ class OracleEnv:
 
     # ---- helpers to inject a golden-vector row as the state of env i -------------------------
     def set_env(self, i, state13, waypoints, final_yaw, last_distance, waypoint_index, fwr, counter, counter_activated,
-                current_step, ep_return=0.0, episode=1):
+                current_step, ep_return=0.0, episode=1, k_env=0):
         self.fstate[0:13, i] = state13
         self.fstate[F_FINAL_YAW, i] = final_yaw
         self.fstate[F_LAST_DISTANCE, i] = -1.0 if (last_distance is None or np.isnan(last_distance)) else last_distance
@@ -152,7 +158,7 @@ class OracleEnv:
         self.fstate[F_WP0:F_WP0 + 3 * wp.shape[0], i] = wp.reshape(-1)
         self.istate[I_STEP, i] = current_step
         self.istate[I_COUNTER, i] = counter
-        self.istate[I_FLAGS, i] = (int(waypoint_index) & 255) | (FLAGBIT_FWR if fwr else 0) | (FLAGBIT_COUNTER_ACTIVE if counter_activated else 0)
+        self.istate[I_FLAGS, i] = (int(waypoint_index) & 15) | ((int(k_env) & 15) << 4) | (FLAGBIT_FWR if fwr else 0) | (FLAGBIT_COUNTER_ACTIVE if counter_activated else 0)
         self.istate[I_EPISODE, i] = episode
 
 

@@ -15,6 +15,8 @@ INFO_TERMINATED, INFO_TRUNCATED, INFO_SUCCESS, INFO_STOPPED, INFO_CRASHED, INFO_
 F_FINAL_YAW, F_LAST_DISTANCE, F_EP_RETURN, F_WP0 = 13, 14, 15, 16
 I_STEP, I_COUNTER, I_FLAGS, I_EPISODE, I_NFIELDS = 0, 1, 2, 3, 4
 FLAGBIT_FWR, FLAGBIT_COUNTER_ACTIVE = 256, 512
+TASK_V2_SCALED20, TASK_V1_SCALED17, TASK_V1_RAW17 = 0, 1, 2
+TASKS = {"v2": TASK_V2_SCALED20, "v1_scaled": TASK_V1_SCALED17, "v1_raw": TASK_V1_RAW17}
 
 
 class Vehicle(C.Structure):
@@ -61,6 +63,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "amenv_version": (C.c_char_p, []),
     "amenv_default_config": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(Config)]),
+    "amenv_config_set_task": (C.c_int, [C.POINTER(Config), C.c_int32]),
     "amenv_dims": (C.c_int, [C.POINTER(Config)] + [C.POINTER(C.c_int32)] * 4),
     "amenv_bytes_per_env_step": (C.c_int64, [C.POINTER(Config)]),
     "amenv_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(_P)]),
@@ -96,9 +99,11 @@ def load():
     return _lib
 
 
-def default_config(vehicle="quad", num_envs=1):
+def default_config(vehicle="quad", num_envs=1, task="v2"):
     cfg = Config()
     rc = load().amenv_default_config(vehicle.encode(), num_envs, C.byref(cfg))
+    if rc == 0 and task != "v2":
+        rc = load().amenv_config_set_task(C.byref(cfg), TASKS[task])
     if rc != 0:
         raise AmenvError(load().amenv_last_error(None).decode())
     return cfg

@@ -18,7 +18,7 @@ using namespace amenv_dev;
 struct amenv {
   amenv_config cfg;
   int device = -1;
-  int obs_dim = kObsDim, act_dim = kActDim, nf = 0;
+  int obs_dim = 20, act_dim = kActDim, nf = 0;
   void* blob = nullptr;            // tiled episode state (amenv_kernels.hpp "Data layout")
   unsigned long long* stats = nullptr;
   size_t blob_bytes = 0, fbytes = 0, ibytes = 0;
@@ -164,7 +164,7 @@ HotParams<T, NR> make_hot(const amenv& e) {
   P.mass_f = float(v.mass); P.g_f = float(v.g); P.mscale_f = float(v.moment_scale);
   P.n_rotors = v.n_rotors; P.substeps = ns;
   P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit;
-  P.flags = c.flags; P.K = c.task.num_waypoints;
+  P.flags = c.flags; P.K = c.task.num_waypoints; P.raw_obs = c.task.variant == AMENV_TASK_V1_RAW17 ? 1 : 0;
   return P;
 }
 
@@ -177,6 +177,9 @@ ColdParams make_cold(const amenv& e) {
   return C;
 }
 
+bool is_v1(const amenv_config* c) { return c->task.variant == AMENV_TASK_V1_SCALED17 || c->task.variant == AMENV_TASK_V1_RAW17; }
+int obs_dim_of(const amenv_config* c) { return is_v1(c) ? 17 : 20; }
+
 int n_float_fields(const amenv_config* c) { return AMENV_F_WP0 + 3 * c->task.num_waypoints + 3 * c->vehicle.n_joints; }
 
 const char* validate(const amenv_config* c) {
@@ -187,7 +190,8 @@ const char* validate(const amenv_config* c) {
   if (c->dtype != AMENV_F32 && c->dtype != AMENV_F64) return "dtype must be AMENV_F32 or AMENV_F64";
   if (c->vehicle.n_rotors < 1 || c->vehicle.n_rotors > AMENV_MAX_ROTORS) return "n_rotors out of range";
   if (c->vehicle.n_joints != 0) return "n_joints != 0 (arm) is not built in this version";
-  if (c->task.variant != AMENV_TASK_V2_SCALED20) return "task variant not built in this version";
+  if (c->task.variant != AMENV_TASK_V2_SCALED20 && !is_v1(c)) return "unknown task variant";
+  if (is_v1(c) && c->task.num_waypoints > 2) return "v1 tasks draw 1..2 waypoints per episode: num_waypoints (storage bound) must be 1 or 2";
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
   if (c->task.max_episode_steps < 1 || c->task.counter_limit < 0) return "bad episode limits";
   if (!(c->task.dt > 0.0) || !(c->vehicle.mass > 0.0)) return "dt and mass must be positive";
@@ -202,31 +206,32 @@ const char* validate(const amenv_config* c) {
   return nullptr;
 }
 
-template <typename T, int NROT, int KW>
+template <typename T, int NROT, int KW, int VAR>
 hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed) {
   const HotParams<T, NROT> P = make_hot<T, NROT>(e);
   const ColdParams C = make_cold(e);
   const int bs = e.block, n_pad = e.n_tiles * 64;
   const dim3 grid((n_pad + bs - 1) / bs), block(bs);
-  const size_t lds = size_t(bs) * kObsDim * sizeof(float);
+  const size_t lds = size_t(bs) * ObsDim<VAR>::value * sizeof(float);
   const StepTail tl{io.terminal_obs, io.ep_return, io.ep_len, io.stats};
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
   if (T_steps > 0) {
-    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C);
+    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C);
   } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
-    hipExtLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward, io.done,
+    hipExtLaunchKernelGGL((step_kernel<T, NROT, KW, VAR>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward, io.done,
                           io.info, tl, P, C);
   } else {
-    hipLaunchKernelGGL((step_kernel<T, NROT, KW>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C);
+    hipLaunchKernelGGL((step_kernel<T, NROT, KW, VAR>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C);
   }
   return hipGetLastError();
 }
 
 template <typename T, int NROT>
 hipError_t dispatch_k(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed) {
-  if (e.cfg.task.num_waypoints == 1) return launch_step<T, NROT, 1>(e, io, T_steps, s, timed);
-  return launch_step<T, NROT, AMENV_MAX_WAYPOINTS>(e, io, T_steps, s, timed);
+  if (is_v1(&e.cfg)) return launch_step<T, NROT, 2, VAR_V1>(e, io, T_steps, s, timed);   // v1: up to 2 waypoints per episode
+  if (e.cfg.task.num_waypoints == 1) return launch_step<T, NROT, 1, VAR_V2>(e, io, T_steps, s, timed);
+  return launch_step<T, NROT, AMENV_MAX_WAYPOINTS, VAR_V2>(e, io, T_steps, s, timed);
 }
 
 template <typename T>
@@ -240,7 +245,7 @@ hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStrea
 template <typename T>
 hipError_t launch_reset(const amenv& e, const uint8_t* mask, float* obs, int pad_only, hipStream_t s) {
   const int bs = 256, n_pad = e.n_tiles * 64;
-  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, e.cfg.task.num_waypoints, e.tile_bytes,
+  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, e.cfg.task.num_waypoints, e.cfg.task.variant, e.tile_bytes,
                      make_cold(e), e.blob, mask, obs, pad_only);
   return hipGetLastError();
 }
@@ -280,9 +285,23 @@ int amenv_default_config(const char* vehicle_name, int32_t num_envs, amenv_confi
   return AMENV_OK;
 }
 
+int amenv_config_set_task(amenv_config* cfg, int32_t variant) {
+  if (!cfg) return AMENV_ERR_INVALID;
+  if (variant == AMENV_TASK_V2_SCALED20) {
+    fill_task_defaults(&cfg->task, 1);
+  } else if (variant == AMENV_TASK_V1_SCALED17 || variant == AMENV_TASK_V1_RAW17) {
+    fill_task_defaults(&cfg->task, 2);        // storage bound; K in {1,2} is drawn per episode (v1/rl_env_scaledObs.py:38)
+    cfg->task.variant = variant;
+    cfg->task.max_episode_steps = 1200;       // v1/rl_env_scaledObs.py:43
+  } else {
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_config_set_task: unknown variant");
+  }
+  return AMENV_OK;
+}
+
 int amenv_dims(const amenv_config* cfg, int32_t* obs_dim, int32_t* act_dim, int32_t* nff, int32_t* nif) {
   if (!cfg) return AMENV_ERR_INVALID;
-  if (obs_dim) *obs_dim = kObsDim;
+  if (obs_dim) *obs_dim = obs_dim_of(cfg);
   if (act_dim) *act_dim = kActDim;
   if (nff) *nff = n_float_fields(cfg);
   if (nif) *nif = AMENV_I_NFIELDS;
@@ -296,7 +315,7 @@ int64_t amenv_bytes_per_env_step(const amenv_config* cfg) {
   const int64_t K = cfg->task.num_waypoints;
   const int64_t rd = ts * (13 /*state*/ + 1 /*final_yaw*/ + 1 /*last_distance*/ + 1 /*ep_return*/ + 3 * K /*waypoints*/) +
                      4 * 3 /*step,counter,flags*/ + 4 * kActDim /*action*/;
-  const int64_t wr = ts * (13 + 1 + 1) + 4 * 3 + 4 * kObsDim /*obs*/ + ts /*reward*/ + 1 /*done*/ + 4 /*info*/;
+  const int64_t wr = ts * (13 + 1 + 1) + 4 * 3 + 4 * obs_dim_of(cfg) /*obs*/ + ts /*reward*/ + 1 /*done*/ + 4 /*info*/;
   return rd + wr;
 }
 
@@ -340,9 +359,10 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     return fail(nullptr, AMENV_ERR_ALLOC, msg);
   }
   char buf[160];
-  std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
+  std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
-                cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS, e->block);
+                is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2", e->block);
+  e->obs_dim = obs_dim_of(cfg);
   e->kname = buf;
   *out = e;
   return AMENV_OK;
@@ -384,9 +404,9 @@ int amenv_observe(amenv* e, float* obs_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int n = e->cfg.num_envs, bs = 256, K = e->cfg.task.num_waypoints;
   if (e->cfg.dtype == AMENV_F64) {
-    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->tile_bytes, (const void*)e->blob, obs_out);
+    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->tile_bytes, (const void*)e->blob, obs_out);
   } else {
-    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->tile_bytes, (const void*)e->blob, obs_out);
+    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->tile_bytes, (const void*)e->blob, obs_out);
   }
   AMENV_HIP(e, hipGetLastError());
   return AMENV_OK;

@@ -90,30 +90,44 @@ __device__ __forceinline__ void store_env_episode(int K, char* tile, int lane, c
     if (3 * K > 4 * g) *gptr<T>(tile, lane, 4 + g) = Vec4<T>{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
 }
 
-// Stage this lane's 80-B observation row in LDS.  Row stride 80 B: the 8 lanes of a
-// ds_write_b128 group land on banks {0,20,8,28,16,4,24,12}+0..3 -> conflict-free.
+// Stage this lane's observation row in LDS.  OD = 20 (80-B rows): five ds_write_b128, the 8 lanes of a group land on banks
+// {0,20,8,28,16,4,24,12}+0..3 -> conflict-free.  OD = 17 (68-B rows, not 16-B aligned): dword writes, stride 17 is conflict-free.
+template <int OD>
 __device__ __forceinline__ void stage_obs(float* lds_row, const float* o) {
-  float4* d = reinterpret_cast<float4*>(lds_row);
+  if constexpr (OD % 4 == 0) {
+    float4* d = reinterpret_cast<float4*>(lds_row);
 #pragma unroll
-  for (int j = 0; j < 5; j++) d[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+    for (int j = 0; j < OD / 4; j++) d[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < OD; j++) lds_row[j] = o[j];
+  }
 }
 
-// Copy the block's staged rows to global memory: consecutive lanes write consecutive float4
-// (1 KiB per wave instruction), rows_valid*5 float4 in all.
+// Copy the block's staged rows to global memory: consecutive lanes write consecutive float4 (1 KiB per wave instruction).
+// The block's region starts 16-B aligned (blockDim.x * OD * 4 bytes per block, blockDim.x a multiple of 64).
+template <int OD>
 __device__ __forceinline__ void flush_obs(const float* lds, float* __restrict__ obs_block, int rows_valid) {
   const float4* s = reinterpret_cast<const float4*>(lds);
   float4* d = reinterpret_cast<float4*>(obs_block);
-  const int nvec = rows_valid * (kObsDim / 4);
+  const int nflt = rows_valid * OD, nvec = nflt >> 2;
   const int bs = int(blockDim.x);
-  // all five LDS reads first (unconditional: the staging area is always blockDim.x rows), then the
-  // predicated stores: one LDS round trip instead of five dependent ones
-  float4 v[kObsDim / 4];
+  constexpr int PASSES = (OD + 3) / 4;
+  // all LDS reads first (unconditional: the staging area always holds blockDim.x rows), then the predicated stores
+  float4 v[PASSES];
 #pragma unroll
-  for (int j = 0; j < kObsDim / 4; j++) v[j] = s[j * bs + int(threadIdx.x)];
+  for (int j = 0; j < PASSES; j++) {
+    const int f = j * bs + int(threadIdx.x);
+    v[j] = (4 * f + 3 < bs * OD) ? s[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
-  for (int j = 0; j < kObsDim / 4; j++) {
+  for (int j = 0; j < PASSES; j++) {
     const int f = j * bs + int(threadIdx.x);
     if (f < nvec) d[f] = v[j];
+  }
+  if constexpr (OD % 4 != 0) {  // a partial last block can leave up to 3 floats past the last full float4
+    const int t = 4 * nvec + int(threadIdx.x);
+    if (t < nflt) obs_block[t] = lds[t];
   }
 }
 
@@ -172,15 +186,17 @@ struct StepIO {
 
 // Everything one lane does for one control step, state in registers.  Returns info bits;
 // `o` holds the observation to publish (post-reset when the env was auto-reset).
-template <typename T, int NROT, int KW>
+template <typename T, int NROT, int KW, int VAR>
 __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const ColdParams& C, Env<T, KW>& e, const float4 a, int i,
                                               bool active, T& reward, float* o, const StepIO& io, char* tile, int lane,
                                               bool have_episode, bool& was_reset, int& ep_len_out, float& ep_ret_out) {
+  constexpr int OD = ObsDim<VAR>::value;
   const int K = KW == 1 ? 1 : P.K;
   dynamics<T, NROT, KW>(P, e, a.x, a.y, a.z, a.w);
-  uint32_t bits = task_step<T, KW>(P, e, reward);
+  uint32_t bits;
+  if constexpr (VAR == VAR_V1) { bits = task_step_v1<T, KW>(P, e, reward); } else { bits = task_step<T, KW>(P, e, reward); }
   e.ep_return += reward;
-  observe<T, KW>(K, e, o);
+  if constexpr (VAR == VAR_V1) { observe_v1<T, KW>(P.raw_obs != 0, e, o); } else { observe<T, KW>(K, e, o); }
   was_reset = false;
   ep_len_out = 0; ep_ret_out = 0.0f;
   const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
@@ -192,16 +208,21 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
       ep_len_out = e.step; ep_ret_out = float(e.ep_return);
       if (active) {
         if (io.terminal_obs) {
-          float4* t = reinterpret_cast<float4*>(io.terminal_obs + size_t(i) * kObsDim);
+          float* t = io.terminal_obs + size_t(i) * OD;
+          if constexpr (OD % 4 == 0) {
 #pragma unroll
-          for (int j = 0; j < 5; j++) t[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+            for (int j = 0; j < OD / 4; j++) reinterpret_cast<float4*>(t)[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < OD; j++) t[j] = o[j];
+          }
         }
         if (io.ep_return) io.ep_return[i] = ep_ret_out;
         if (io.ep_len) io.ep_len[i] = ep_len_out;
       }
       if (resets) {
-        reset_from_words<T, KW>(C, K, e, r);
-        observe<T, KW>(K, e, o);
+        if constexpr (VAR == VAR_V1) { reset_from_words_v1<T, KW>(K, e, r); observe_v1<T, KW>(P.raw_obs != 0, e, o); }
+        else { reset_from_words<T, KW>(C, K, e, r); observe<T, KW>(K, e, o); }
         bits |= AMENV_INFO_WAS_RESET;
         was_reset = true;
       }
@@ -235,7 +256,7 @@ constexpr int kStampSlots = 8, kStampWaves = 64, kStampBase = 16;
 struct StepTail { float* terminal_obs; float* ep_return; int32_t* ep_len; unsigned long long* stats; };
 struct Head { void* blob; uint32_t tile_bytes; int32_t n; };
 
-template <typename T, int NROT, int KW>
+template <typename T, int NROT, int KW, int VAR>
 __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
                                                    float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
                                                    uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C) {
@@ -258,8 +279,8 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
   AMENV_STAMP(1);          // loads issued
   AMENV_STAMP_DRAIN();
   AMENV_STAMP(2);          // loads landed
-  T reward; float o[kObsDim]; bool was_reset; int ep_len; float ep_ret;
-  uint32_t bits = step_lane<T, NROT, KW>(P, C, e, a, i, active, reward, o, io, tile, lane, false, was_reset, ep_len, ep_ret);
+  T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
+  uint32_t bits = step_lane<T, NROT, KW, VAR>(P, C, e, a, i, active, reward, o, io, tile, lane, false, was_reset, ep_len, ep_ret);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   AMENV_STAMP(3);          // dynamics + task + obs computed
   accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
@@ -273,17 +294,17 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
   AMENV_STAMP(4);          // state/outputs stores issued
 #ifdef AMENV_DIAG_DIRECT_OBS
   if (active) {
-    float4* d = reinterpret_cast<float4*>(io.obs + size_t(i) * kObsDim);
+    float4* d = reinterpret_cast<float4*>(io.obs + size_t(i) * ObsDim<VAR>::value);
 #pragma unroll
     for (int j = 0; j < 5; j++) d[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
   }
   (void)lds;
 #else
-  stage_obs(lds + threadIdx.x * kObsDim, o);
+  stage_obs<ObsDim<VAR>::value>(lds + threadIdx.x * ObsDim<VAR>::value, o);
   __syncthreads();
   const int row0 = blockIdx.x * BS;
   const int rows = min(BS, hd.n - row0);
-  flush_obs(lds, io.obs + size_t(row0) * kObsDim, rows);
+  flush_obs<ObsDim<VAR>::value>(lds, io.obs + size_t(row0) * ObsDim<VAR>::value, rows);
 #endif
   AMENV_STAMP(5);          // obs flushed
   AMENV_STAMP(6);
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
 
 // n_steps control steps per launch with open-loop actions [T][N][4]; per-step outputs [T][N]...
 // State stays in registers across steps: HBM traffic per env-step drops to action + outputs.
-template <typename T, int NROT, int KW>
+template <typename T, int NROT, int KW, int VAR>
 __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
                                                       float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
                                                       uint32_t* __restrict__ info, int n_steps, const StepTail tl, const HotParams<T, NROT> P,
@@ -321,8 +342,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
   StepIO io_t = io; io_t.terminal_obs = nullptr; io_t.ep_return = nullptr; io_t.ep_len = nullptr;
   for (int t = 0; t < n_steps; t++) {
     const float4 a = io.actions[size_t(t) * n + min(i, hd.n - 1)];
-    T reward; float o[kObsDim]; bool was_reset; int ep_len; float ep_ret;
-    uint32_t bits = step_lane<T, NROT, KW>(P, C, e, a, i, active, reward, o, io_t, tile, lane, any_reset, was_reset, ep_len, ep_ret);
+    T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
+    uint32_t bits = step_lane<T, NROT, KW, VAR>(P, C, e, a, i, active, reward, o, io_t, tile, lane, any_reset, was_reset, ep_len, ep_ret);
     any_reset |= was_reset;
     const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
     accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
@@ -332,9 +353,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
       if (io.info) io.info[size_t(t) * n + i] = bits;
     }
     if (io.obs) {
-      stage_obs(lds + threadIdx.x * kObsDim, o);
+      stage_obs<ObsDim<VAR>::value>(lds + threadIdx.x * ObsDim<VAR>::value, o);
       __syncthreads();
-      flush_obs(lds, io.obs + (size_t(t) * n + row0) * kObsDim, rows);
+      flush_obs<ObsDim<VAR>::value>(lds, io.obs + (size_t(t) * n + row0) * ObsDim<VAR>::value, rows);
       __syncthreads();
     }
   }
@@ -345,8 +366,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
 // WaypointQuadEnv.reset for masked envs (mask null = all) + observation of every env.
 // Launched over whole tiles: padding lanes (i >= n) are always reset so that they hold a valid state.
 template <typename T>
-__global__ void reset_kernel(int n, int K, uint32_t tile_bytes, const ColdParams C, void* __restrict__ blob,
+__global__ void reset_kernel(int n, int K, int variant, uint32_t tile_bytes, const ColdParams C, void* __restrict__ blob,
                              const uint8_t* __restrict__ mask, float* __restrict__ obs, int pad_only) {
+  const bool v1 = variant != AMENV_TASK_V2_SCALED20;
+  const int od = v1 ? 17 : 20;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool active = i < n;
@@ -355,29 +378,31 @@ __global__ void reset_kernel(int n, int K, uint32_t tile_bytes, const ColdParams
   load_env<T, AMENV_MAX_WAYPOINTS>(K, tile, lane, e);
   const bool do_reset = active ? (!pad_only && (!mask || mask[i])) : true;  // pad_only: amenv_create's init pass
   if (do_reset) {
-    reset_env<T, AMENV_MAX_WAYPOINTS>(C, K, e, C.gid0 + i);
+    reset_env<T, AMENV_MAX_WAYPOINTS>(C, K, v1, e, C.gid0 + i);
     store_env_step<T, AMENV_MAX_WAYPOINTS>(tile, lane, e);
     store_env_episode<T, AMENV_MAX_WAYPOINTS>(K, tile, lane, e);
   }
   if (obs && active) {
-    float o[kObsDim];
-    observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
-#pragma unroll
-    for (int j = 0; j < kObsDim; j++) obs[size_t(i) * kObsDim + j] = o[j];
+    float o[kObsDimMax];
+    if (v1) observe_v1<T, AMENV_MAX_WAYPOINTS>(variant == AMENV_TASK_V1_RAW17, e, o);
+    else observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
+    for (int j = 0; j < od; j++) obs[size_t(i) * od + j] = o[j];
   }
 }
 
 // _get_observation of the current state for every env (no stepping).
 template <typename T>
-__global__ void observe_kernel(int n, int K, uint32_t tile_bytes, const void* __restrict__ blob, float* __restrict__ obs) {
+__global__ void observe_kernel(int n, int K, int variant, uint32_t tile_bytes, const void* __restrict__ blob, float* __restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const bool v1 = variant != AMENV_TASK_V2_SCALED20;
+  const int od = v1 ? 17 : 20;
   Env<T, AMENV_MAX_WAYPOINTS> e;
   load_env<T, AMENV_MAX_WAYPOINTS>(K, tile_base(blob, tile_bytes, i), threadIdx.x & 63, e);
-  float o[kObsDim];
-  observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
-#pragma unroll
-  for (int j = 0; j < kObsDim; j++) obs[size_t(i) * kObsDim + j] = o[j];
+  float o[kObsDimMax];
+  if (v1) observe_v1<T, AMENV_MAX_WAYPOINTS>(variant == AMENV_TASK_V1_RAW17, e, o);
+  else observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
+  for (int j = 0; j < od; j++) obs[size_t(i) * od + j] = o[j];
 }
 
 // amenv_get_state / amenv_set_state: the public struct-of-arrays view (fstate [NF][N] T, istate [4][N] i32)

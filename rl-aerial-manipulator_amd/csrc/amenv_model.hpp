@@ -24,8 +24,10 @@
 
 namespace amenv_dev {
 
-constexpr int kObsDim = 20;  // v2 observation
 constexpr int kActDim = 4;
+enum TaskVar { VAR_V2 = 0, VAR_V1 = 1 };                 // v2/rl_env_scaledObs.py | v1/rl_env_scaledObs.py + v1/rl_env.py
+template <int VAR> struct ObsDim { static constexpr int value = VAR == VAR_V1 ? 17 : 20; };
+constexpr int kObsDimMax = 20;
 
 // ---- kernel-argument constants (uniform: they live in SGPRs) ----------------------------------
 // Hot parameters are kept COMPACT (rotor-count-sized mixer, symmetric inertia) so that one batch of
@@ -43,7 +45,8 @@ struct HotParams {
   int32_t n_rotors;                 // used only by the generic (NR = AMENV_MAX_ROTORS) instantiation
   int32_t substeps, max_steps, counter_limit;
   uint32_t flags;
-  int32_t K;                        // waypoints per episode (<= KW of the instantiation)
+  int32_t K;                        // waypoints per episode (<= KW of the instantiation); v1: storage bound
+  int32_t raw_obs;                  // v1 only: 1 = v1/rl_env.py (unscaled observation)
 };
 
 // Parameters only the reset path needs (cold: loaded when a lane actually resets).
@@ -201,7 +204,7 @@ __device__ __forceinline__ void current_waypoint(int K, const Env<T, KW>& e, int
 // _get_observation (rl_env_scaledObs.py:98-121)
 template <typename T, int KW>
 __device__ __forceinline__ void observe(int K, const Env<T, KW>& e, float* o) {
-  const int idx = e.flags & 255;
+  const int idx = e.flags & 15;
   T cx, cy, cz;
   current_waypoint(K, e, idx, cx, cy, cz);
   // scalings as multiplications by the rounded reciprocal (<= 1 ulp from the reference's divisions)
@@ -225,7 +228,7 @@ template <typename T, int KW, typename PT>
 __device__ __forceinline__ uint32_t task_step(const PT& P, Env<T, KW>& e, T& reward) {
   const int K = KW == 1 ? 1 : P.K;
   uint32_t bits = 0;
-  int idx = e.flags & 255;
+  int idx = e.flags & 15;
   bool fwr = (e.flags & AMENV_FLAGBIT_FWR) != 0;
   bool cact = (e.flags & AMENV_FLAGBIT_COUNTER_ACTIVE) != 0;
   const bool truncated = e.step >= P.max_steps;                         // :144
@@ -303,8 +306,110 @@ __device__ __forceinline__ uint32_t task_step(const PT& P, Env<T, KW>& e, T& rew
       bits |= AMENV_INFO_TERMINATED | AMENV_INFO_OOB;
     }
   }
-  e.flags = (idx & 255) | (fwr ? AMENV_FLAGBIT_FWR : 0) | (cact ? AMENV_FLAGBIT_COUNTER_ACTIVE : 0);
+  e.flags = (idx & 15) | (fwr ? AMENV_FLAGBIT_FWR : 0) | (cact ? AMENV_FLAGBIT_COUNTER_ACTIVE : 0);
   return bits;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return float(r >> 8) * 5.9604644775390625e-08f; }   // [0,1), 24 bits, exact
+
+// ---- v1 task (v1/rl_env_scaledObs.py, v1/rl_env.py): 17-D observation, per-episode waypoint count in flags bits 4-7 ----
+template <typename T, int KW>
+__device__ __forceinline__ void observe_v1(bool raw, const Env<T, KW>& e, float* o) {        // :65-83
+  const int idx = e.flags & 15, K = (e.flags >> 4) & 15;
+  T cx, cy, cz;
+  current_waypoint(K, e, idx, cx, cy, cz);
+  const T c10 = raw ? T(1) : T(0.1), c5 = raw ? T(1) : T(0.2), c2 = raw ? T(1) : T(0.5);
+  o[0] = float(e.px * c10); o[1] = float(e.py * c10); o[2] = float(e.pz * c10);
+  o[3] = float(e.vx * c5); o[4] = float(e.vy * c5); o[5] = float(e.vz * c5);
+  o[6] = float(e.qw); o[7] = float(e.qx); o[8] = float(e.qy); o[9] = float(e.qz);
+  o[10] = float(e.wx * c5); o[11] = float(e.wy * c5); o[12] = float(e.wz * c5);
+  o[13] = float((cx - e.px) * c2); o[14] = float((cy - e.py) * c2); o[15] = float((cz - e.pz) * c2);
+  o[16] = idx >= K - 1 ? 1.0f : 0.0f;                                                         // :80 is_final
+}
+
+// One v1 step after the dynamics update: v1/rl_env_scaledObs.py:93-140 (+ _calculate_reward :142-168).
+template <typename T, int KW, typename PT>
+__device__ __forceinline__ uint32_t task_step_v1(const PT& P, Env<T, KW>& e, T& reward) {
+  uint32_t bits = 0;
+  int idx = e.flags & 15;
+  const int K = (e.flags >> 4) & 15;
+  if (P.flags & AMENV_FLAG_NAN_GUARD) {
+    const T sum = e.px + e.py + e.pz + e.vx + e.vy + e.vz + e.qw + e.qx + e.qy + e.qz + e.wx + e.wy + e.wz;
+    if (!finite_(sum)) {
+      if (e.step >= P.max_steps) bits |= AMENV_INFO_TRUNCATED;
+      e.step += 1; reward = T(-100);
+      return bits | AMENV_INFO_TERMINATED | AMENV_INFO_NONFINITE;
+    }
+  }
+  T cx, cy, cz;
+  current_waypoint(K, e, idx, cx, cy, cz);
+  const T dx = e.px - cx, dy = e.py - cy, dz = e.pz - cz;
+  const T dist = sqrt_(dot3_(dx, dy, dz, dx, dy, dz));                  // :148
+  const T v2 = dot3_(e.vx, e.vy, e.vz, e.vx, e.vy, e.vz);
+  const T w2 = dot3_(e.wx, e.wy, e.wz, e.wx, e.wy, e.wz);
+  const T vn = sqrt_(v2), wn = sqrt_(w2);
+  T r_speed = T(-0.1) * v2;                                             // :152
+  if (wn > T(0.1)) r_speed -= T(0.01) * w2;                             // :153-154
+  T r_prog = T(0);
+  if (e.last_distance >= T(0)) {                                        // :158-164
+    r_prog = T(20) * (e.last_distance - dist);
+    if (r_prog > T(0)) r_prog += T(2);
+  }
+  e.last_distance = dist;                                               // :166
+  reward = ((T(-2) * dist + r_speed) + T(-0.1)) + r_prog;               // :151,155,168
+  // approach shaping: velocity component toward the waypoint (:102-110); dist == 0 -> NaN -> neither branch
+  const T vtw = -dot3_(e.vx, e.vy, e.vz, dx, dy, dz) * rcp_(dist);
+  if (dist < T(0.5)) {
+    if (vtw > T(0.1)) reward += T(10);
+    else if (vtw < T(0.1)) reward -= T(10);
+  }
+  bool final_reach = false;
+  if (dist < T(0.1)) {                                                  // :111-124
+    reward += T(100); idx += 1;
+    if (idx >= K) {
+      const T rot_b = wn < T(0.1) ? T(100) : T(-20) * wn;               // :122
+      const T stop_b = vn < T(0.1) ? T(100) : T(-10) * vn;              // :123
+      reward = ((reward + T(400)) + stop_b) + rot_b;                    // :124: returns BEFORE current_step += 1, truncated False
+      bits = AMENV_INFO_TERMINATED | AMENV_INFO_SUCCESS | (vn < T(0.1) ? AMENV_INFO_STOPPED : 0u);
+      final_reach = true;
+    }
+  }
+  if (!final_reach) {
+    if (e.step >= P.max_steps) bits |= AMENV_INFO_TRUNCATED;           // :126
+    e.step += 1;                                                        // :127
+    if (e.pz < T(0.1)) {                                                // :131-136
+      reward -= T(100);
+      if (e.vz < T(0)) reward += e.vz * T(100);
+      bits |= AMENV_INFO_TERMINATED | AMENV_INFO_CRASHED;
+    } else if (sqrt_(dot3_(e.px, e.py, e.pz, e.px, e.py, e.pz)) > T(10)) {  // :137-139
+      reward -= T(100);
+      bits |= AMENV_INFO_TERMINATED | AMENV_INFO_OOB;
+    }
+  }
+  e.flags = (idx & 15) | (K << 4);
+  return bits;
+}
+
+// v1 reset (v1/rl_env_scaledObs.py:32-63) from the 12 Philox words; DESIGN.md draw table "v1".
+template <typename T, int KW>
+__device__ __forceinline__ void reset_from_words_v1(int Kmax, Env<T, KW>& e, const uint32_t* r) {
+  int K = 1 + int(r[2] >> 31);                                          // :38 randint(1,3)
+  K = K < Kmax ? K : Kmax;
+  e.px = T(fmaf(2.0f, u01(r[0]), -1.0f)); e.py = T(fmaf(2.0f, u01(r[1]), -1.0f)); e.pz = T(fmaf(1.0f, u01(r[3]), 1.0f));  // :36-37
+  e.vx = e.vy = e.vz = T(0);
+  e.qw = T(1); e.qx = e.qy = e.qz = T(0);
+  e.wx = e.wy = e.wz = T(0);
+#pragma unroll
+  for (int k = 0; k < KW; k++) {
+    const bool on = k < K && k < 2;
+    const int b = 4 + 3 * (k < 2 ? k : 0);
+    e.wp[k][0] = on ? T(fmaf(2.0f, u01(r[b]), -1.0f)) : T(0);          // :53-63
+    e.wp[k][1] = on ? T(fmaf(2.0f, u01(r[b + 1]), -1.0f)) : T(0);
+    e.wp[k][2] = on ? T(fmaf(2.0f, u01(r[b + 2]), 1.0f)) : T(0);
+  }
+  e.final_yaw = T(0); e.last_distance = T(-1); e.ep_return = T(0);
+  e.step = 0; e.counter = 0; e.flags = K << 4;
+  e.episode += 1;
 }
 
 // ---- counter-based reset RNG: Philox4x32-10, key = seed, counter = (global env id, episode, block)
@@ -321,7 +426,6 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ float u01(uint32_t r) { return float(r >> 8) * 5.9604644775390625e-08f; }
 
 // WaypointQuadEnv.reset (rl_env_scaledObs.py:40-79) with the DESIGN.md draw table.  All draws
 // are formed in fp32 with explicit fmaf so the CPU oracle reproduces them bit for bit.
@@ -403,10 +507,11 @@ __device__ __forceinline__ void reset_from_words(const ColdParams& P, int K, Env
 }
 
 template <typename T, int KW>
-__device__ __forceinline__ void reset_env(const ColdParams& P, int K, Env<T, KW>& e, int64_t gid) {
+__device__ __forceinline__ void reset_env(const ColdParams& P, int K, bool v1, Env<T, KW>& e, int64_t gid) {
   uint32_t r[12];
   reset_words_serial(P, gid, e.episode, r);
-  reset_from_words<T, KW>(P, K, e, r);
+  if (v1) reset_from_words_v1<T, KW>(K, e, r);
+  else reset_from_words<T, KW>(P, K, e, r);
 }
 
 }  // namespace amenv_dev

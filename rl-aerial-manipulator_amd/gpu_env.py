@@ -32,12 +32,12 @@ class GpuWaypointEnv:
 
     def __init__(self, num_envs, device=0, vehicle="quad", seed=0, dtype="f32", auto_reset=True, nan_guard=False,
                  num_waypoints=1, env_id_offset=0, block_size=0, max_episode_steps=None, counter_limit=None,
-                 rk4_substeps=1, config=None):
+                 rk4_substeps=1, task="v2", config=None):
         self.lib = L.load()
         self.device_index = _dev_index(device)
         self.device = torch.device("cuda", self.device_index)
         if config is None:
-            cfg = L.default_config(vehicle, num_envs)
+            cfg = L.default_config(vehicle, num_envs, task)   # task: "v2" | "v1_scaled" | "v1_raw" (which reference env file)
             cfg.seed = seed
             cfg.dtype = L.F64 if dtype in ("f64", torch.float64) else L.F32
             cfg.flags = (L.FLAG_AUTO_RESET if auto_reset else 0) | (L.FLAG_NAN_GUARD if nan_guard else 0)
@@ -48,7 +48,7 @@ class GpuWaypointEnv:
                 cfg.task.max_episode_steps = max_episode_steps
             if counter_limit is not None:
                 cfg.task.counter_limit = counter_limit
-            if num_waypoints != 1:
+            if num_waypoints != 1 and task == "v2":
                 import math
                 cfg.task.num_waypoints = num_waypoints
                 for k in range(1, num_waypoints + 1):

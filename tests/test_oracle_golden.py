@@ -174,3 +174,45 @@ def test_auto_reset_semantics():
     assert env.istate[O.I_EPISODE, 0] == 6 and env.istate[O.I_STEP, 0] == 0
     assert np.array_equal(out["obs"][0], env.observe()[0])
     assert env.fstate[2, 0] >= 1.0  # fresh start height
+
+
+# ---- v1 envs (17-D obs): v1/rl_env_scaledObs.py (scaled) and v1/rl_env.py (raw) --------------------------------------
+@pytest.mark.parametrize("tag,variant", [("v1s", O.TASK_V1_SCALED17), ("v1r", O.TASK_V1_RAW17)])
+@pytest.mark.parametrize("name", G.V1_EPISODES)
+def test_v1_teacher_forced_episode(tag, variant, name):
+    d = G.load(f"{tag}_{name}")
+    T = d["actions"].shape[0]
+    cfg = O.reference_quad_config(num_envs=T, flags=0, variant=variant)
+    env = O.OracleEnv(cfg)
+    assert env.obs_dim == 17
+    G.fill_blob(env.fstate, env.istate, d, per_env_k=True)
+    out = env.step(d["actions"])
+    assert np.abs(env.fstate[0:13].T - d["state"][1:]).max() < STATE_ATOL
+    assert np.array_equal(out["info"] & 63, d["info_bits"]), np.nonzero((out["info"] & 63) != d["info_bits"])
+    assert np.array_equal(env.istate[O.I_STEP], d["var_current_step"][1:])       # final reach returns before the increment
+    assert np.array_equal(env.istate[O.I_FLAGS] & 15, d["var_waypoint_index"][1:])
+    np.testing.assert_allclose(out["obs"], d["obs"], rtol=OBS_RTOL, atol=OBS_ATOL)
+    assert out["obs"].shape[1] == 17 and set(np.unique(out["obs"][:, 16])) <= {0.0, 1.0}
+    assert np.abs(out["reward"] - d["reward"]).max() < REWARD_ATOL, np.abs(out["reward"] - d["reward"]).max()
+
+
+def test_v1_reset_distribution_vs_reference():
+    d = G.load("v1_reset_samples")
+    n = 20000
+    env = O.OracleEnv(O.reference_quad_config(num_envs=n, seed=77, variant=O.TASK_V1_SCALED17))
+    obs = env.reset()
+    K = (env.istate[O.I_FLAGS] >> 4) & 15
+    assert set(np.unique(K)) == {1, 2} and abs((K == 2).mean() - 0.5) < 0.02 and abs((d["K"] == 2).mean() - 0.5) < 0.02
+    st, wp0 = env.fstate[0:3].T, env.fstate[O.F_WP0:O.F_WP0 + 3].T
+    assert (np.abs(st[:, :2]) <= 1).all() and (st[:, 2] >= 1).all() and (st[:, 2] < 2).all()
+    assert (wp0[:, 2] >= 1).all() and (wp0[:, 2] <= 3).all() and (np.abs(wp0[:, :2]) <= 1).all()
+    from scipy import stats
+    for c in range(3):
+        assert stats.ks_2samp(st[:, c], d["start"][:, c]).pvalue > 1e-3
+        assert stats.ks_2samp(wp0[:, c], d["waypoints"][:, 0, c]).pvalue > 1e-3
+    two = K == 2
+    wp1 = env.fstate[O.F_WP0 + 3:O.F_WP0 + 6].T[two]
+    for c in range(3):
+        assert stats.ks_2samp(wp1[:, c], d["waypoints"][d["K"] == 2][:, 1, c]).pvalue > 1e-3
+    assert (obs[:, 16] == (K == 1)).all()                       # is_final flag of the first observation
+    assert (env.fstate[O.F_WP0 + 3:O.F_WP0 + 6].T[~two] == 0).all()

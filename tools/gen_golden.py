@@ -50,12 +50,13 @@ def _install_gymnasium_stub():
     sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = gym, sp
 
 
-def _import_reference():
+def _import_reference(root=REF_V2, module="rl_env_scaledObs"):
     sys.dont_write_bytecode = True
     _install_gymnasium_stub()
-    sys.path.insert(0, REF_V2)
+    sys.path.insert(0, root)
+    import importlib
     with contextlib.redirect_stdout(io.StringIO()):
-        from rl_env_scaledObs import WaypointQuadEnv  # noqa: E402  (unmodified reference file)
+        WaypointQuadEnv = importlib.import_module(module).WaypointQuadEnv  # unmodified reference file
         from simul_files.model.quadcopter import Quadcopter  # noqa: E402
     return WaypointQuadEnv, Quadcopter
 
@@ -66,6 +67,7 @@ class CheckpointPolicy:
     def __init__(self, path):
         import torch
 
+        self.obs_mean = None  # set for VecNormalize-trained policies
         with zipfile.ZipFile(path) as z:
             sd = torch.load(io.BytesIO(z.read("policy.pth")), weights_only=True, map_location="cpu")
         g = lambda k: sd[k].double().numpy()
@@ -83,13 +85,13 @@ class CheckpointPolicy:
 
 
 def env_vars(env):
-    """Scalar per-episode variables of the reference env."""
+    """Scalar per-episode variables of the reference env; the v1 envs lack the hold-phase fields."""
     return dict(
         waypoint_index=int(env.waypoint_index),
         last_distance=float("nan") if env.last_distance is None else float(env.last_distance),
-        fwr=bool(env.final_waypoint_reached),
-        counter=int(env.counter),
-        counter_activated=bool(env.counter_activated),
+        fwr=bool(getattr(env, "final_waypoint_reached", False)),
+        counter=int(getattr(env, "counter", 0) or 0),
+        counter_activated=bool(getattr(env, "counter_activated", False)),
         current_step=int(env.current_step),
     )
 
@@ -126,8 +128,8 @@ def run_episode(env, action_fn, max_steps, stop_on_done=True):
         rec["terminated"].append(bool(term))
         rec["truncated"].append(bool(trunc))
         rec["info_bits"].append(info_to_bits(term, trunc, info))
-        rec["F"].append(float(env.F))
-        rec["M"].append(np.asarray(env.M, dtype=np.float64).copy())
+        rec["F"].append(float(getattr(env, "F", np.nan) if getattr(env, "F", None) is not None else np.nan))
+        rec["M"].append(np.asarray(getattr(env, "M", None) if getattr(env, "M", None) is not None else [np.nan] * 3, dtype=np.float64).copy())
         rec["state"].append(env.quadcopter.state.copy())
         vars_.append(env_vars(env))
         if stop_on_done and (term or trunc):
@@ -144,7 +146,7 @@ def run_episode(env, action_fn, max_steps, stop_on_done=True):
         F=np.asarray(rec["F"], dtype=np.float64),
         M=np.asarray(rec["M"], dtype=np.float64),
         waypoints=np.asarray(env.waypoint_list, dtype=np.float64),
-        final_yaw=np.float64(env.final_yaw),
+        final_yaw=np.float64(getattr(env, "final_yaw", 0.0) or 0.0),
     )
     for k in vars_[0]:
         out["var_" + k] = np.asarray([v[k] for v in vars_])
@@ -159,7 +161,9 @@ def fresh_env(WaypointQuadEnv, seed, start=None, waypoint=None, final_yaw=None):
     if start is not None:
         env.quadcopter.state[0:3] = np.asarray(start, dtype=np.float64)
     if waypoint is not None:
-        env.waypoint_list = [np.asarray(waypoint, dtype=np.float64)]
+        wps = np.asarray(waypoint, dtype=np.float64).reshape(-1, 3)
+        env.waypoint_list = [w.copy() for w in wps]
+        env.num_waypoints = len(env.waypoint_list)
         env.current_waypoint = env.waypoint_list[0]
     if final_yaw is not None:
         env.final_yaw = float(final_yaw)
@@ -191,12 +195,64 @@ def hover_pd(target):
     return fn
 
 
+REF_V1 = "/root/reference/initial-implementation-v1"
+
+
+def main_v1(out, module, tag):
+    """Golden vectors of the v1 envs (17-D obs; `rl_env_scaledObs.py` scaled, `rl_env.py` raw).  Separate process per
+    module: v1 and v2 share module names."""
+    WaypointQuadEnv, _ = _import_reference(REF_V1, module)
+    files = {}
+
+    def save(name, d):
+        np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+        files[name] = dict(steps=int(d["actions"].shape[0]))
+        print(f"  {name}: T={d['actions'].shape[0]} last bits={int(d['info_bits'][-1])} K={d['waypoints'].shape[0]} return={d['reward'].sum():.1f}")
+
+    # PD flight through one / two waypoints: approach shaping (+-10), intermediate waypoint, final reach (+400, bonuses)
+    def chase(t, obs, env):
+        return hover_pd(env.current_waypoint)(t, obs, env)
+
+    env = fresh_env(WaypointQuadEnv, 1, start=[0.0, 0.0, 1.5], waypoint=[[0.5, 0.3, 1.8]])
+    save(f"{tag}_reach1", run_episode(env, chase, 1300))
+    env = fresh_env(WaypointQuadEnv, 2, start=[0.2, -0.4, 1.2], waypoint=[[0.6, 0.1, 1.6], [-0.3, 0.5, 2.2]])
+    save(f"{tag}_reach2", run_episode(env, chase, 1300))
+    # fast fly-through: reaches the final waypoint moving (negative stop bonuses)
+    env = fresh_env(WaypointQuadEnv, 3, start=[0.0, 0.0, 1.5], waypoint=[[0.0, 0.0, 2.4]])
+    save(f"{tag}_flythrough", run_episode(env, lambda t, o, e: np.array([1.6, 0.0, 0.0, 0.01]), 400))
+    env = fresh_env(WaypointQuadEnv, 4, start=[0.1, 0.1, 1.2], waypoint=[[0.5, 0.5, 2.0]])
+    save(f"{tag}_crash", run_episode(env, lambda t, o, e: np.array([0.0, 0.01, -0.01, 0.0]), 400))
+    env = fresh_env(WaypointQuadEnv, 5, start=[0.0, 0.0, 1.5], waypoint=[[-0.8, 0.6, 1.2], [0.3, 0.3, 2.5]])
+    save(f"{tag}_oob", run_episode(env, lambda t, o, e: np.array([2.0, 0.02 if t < 10 else 0.0, 0.0, 0.0]), 1300))
+    env = fresh_env(WaypointQuadEnv, 6, start=[0.0, 0.0, 1.5], waypoint=[[0.9, -0.9, 2.8]])
+    d = run_episode(env, hover_pd([0.0, 0.0, 1.5]), 1300)
+    save(f"{tag}_timelimit", d)
+    print(f"    truncated first at {int(np.argmax(d['truncated']))}")
+    if tag == "v1s":
+        n = 10000
+        np.random.seed(4321)
+        env = WaypointQuadEnv()
+        start = np.zeros((n, 3), np.float32); wp = np.full((n, 2, 3), np.nan, np.float32); K = np.zeros(n, np.uint8)
+        for i in range(n):
+            env.reset()
+            start[i] = env.quadcopter.state[0:3]; K[i] = len(env.waypoint_list)
+            wp[i, :K[i]] = np.asarray(env.waypoint_list)
+        np.savez_compressed(os.path.join(out, "v1_reset_samples.npz"), start=start, waypoints=wp, K=K)
+        files["v1_reset_samples"] = dict(steps=n)
+    with open(os.path.join(out, f"META_{tag}.json"), "w") as f:
+        json.dump(dict(generator=f"tools/gen_golden.py --v1 {module}", reference=f"initial-implementation-v1/{module}.py (unmodified, imported in place)",
+                       numpy=np.__version__, files=files), f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--v1", default=None, choices=["rl_env_scaledObs", "rl_env"], help="record the v1 env of that module instead of v2")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
+    if args.v1:
+        return main_v1(out, args.v1, "v1s" if args.v1 == "rl_env_scaledObs" else "v1r")
 
     WaypointQuadEnv, Quadcopter = _import_reference()
     import scipy
