@@ -247,6 +247,22 @@ int amenv_stats_read(amenv* env, amenv_stats* host_out, int reset, void* stream)
 /* Name, VGPR count etc. of the step kernel chosen for this handle (for bench/profiles). */
 const char* amenv_kernel_name(const amenv* env);
 
+/* ---- observation normaliser: VecNormalize(norm_obs=True, norm_reward=False) (v1/rl_train_vecN.py:10-11) ------------
+ * Running mean / variance / count of [n, dim] f32 observation batches on the device (SB3 2.6.0 RunningMeanStd:
+ * initial mean 0, var 1, count 1e-4; parallel-moments merge), and obs_n = clip((obs-mean)/sqrt(var+eps), -clip, clip)
+ * (SB3 defaults eps = 1e-8, clip = 10).  Third-party semantics, parity unpinned (the reference's vec_normalize.pkl is
+ * a pickle and is not read). */
+typedef struct amenv_obsnorm amenv_obsnorm;
+int amenv_obsnorm_create(int32_t dim, int device, amenv_obsnorm** out);
+int amenv_obsnorm_destroy(amenv_obsnorm* h);
+/* obs_rms.update(obs): merge the moments of this batch (device pointer, row-major [n, dim]). */
+int amenv_obsnorm_update(amenv_obsnorm* h, const float* obs, int64_t n, void* stream);
+/* normalize_obs: out may alias in. */
+int amenv_obsnorm_apply(amenv_obsnorm* h, const float* in, float* out, int64_t n, float clip, double eps, void* stream);
+/* mean[dim], var[dim], count to / from HOST arrays (synchronises): save / load of the statistics. */
+int amenv_obsnorm_get(amenv_obsnorm* h, double* mean, double* var, double* count, void* stream);
+int amenv_obsnorm_set(amenv_obsnorm* h, const double* mean, const double* var, double count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

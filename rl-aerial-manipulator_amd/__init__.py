@@ -11,5 +11,6 @@ from ._lib import AmenvError
 from . import vec_env
 from .gpu_env import GpuWaypointEnv
 from .vec_env import GpuVecEnv
+from .obs_norm import GpuVecNormalize, ObsNormalizer
 
-__all__ = ["GpuWaypointEnv", "GpuVecEnv", "vec_env", "AmenvError", "_lib", "sharding"]
+__all__ = ["GpuWaypointEnv", "GpuVecEnv", "GpuVecNormalize", "ObsNormalizer", "vec_env", "AmenvError", "_lib", "sharding"]

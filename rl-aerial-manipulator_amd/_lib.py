@@ -79,6 +79,12 @@ SYMBOLS = {
     "amenv_observe": (C.c_int, [_P, _P, _P]),
     "amenv_stats_read": (C.c_int, [_P, C.POINTER(Stats), C.c_int, _P]),
     "amenv_kernel_name": (C.c_char_p, [_P]),
+    "amenv_obsnorm_create": (C.c_int, [C.c_int32, C.c_int, C.POINTER(_P)]),
+    "amenv_obsnorm_destroy": (C.c_int, [_P]),
+    "amenv_obsnorm_update": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "amenv_obsnorm_apply": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_double, _P]),
+    "amenv_obsnorm_get": (C.c_int, [_P, _P, _P, _P, _P]),
+    "amenv_obsnorm_set": (C.c_int, [_P, _P, _P, C.c_double, _P]),
 }
 
 _lib = None

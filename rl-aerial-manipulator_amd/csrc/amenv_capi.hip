@@ -12,6 +12,7 @@
 #include <string>
 
 #include "amenv_kernels.hpp"
+#include "amenv_obsnorm.hpp"
 
 using namespace amenv_dev;
 
@@ -491,6 +492,88 @@ int amenv_stats_read(amenv* e, amenv_stats* out, int reset, void* stream) {
   out->success = h[S_SUCCESS]; out->crashed = h[S_CRASHED]; out->oob = h[S_OOB]; out->nonfinite = h[S_NONFINITE];
   out->length_sum = h[S_LENGTH]; out->return_sum_q10 = (int64_t)h[S_RETURN_Q10];
   if (reset) e->steps = 0;
+  return AMENV_OK;
+}
+
+// ---- observation normaliser ------------------------------------------------------------------------------------------
+struct amenv_obsnorm {
+  int dim = 0, device = 0;
+  double* buf = nullptr;   // obsnorm_words(dim) doubles on the device
+};
+
+int amenv_obsnorm_create(int32_t dim, int device, amenv_obsnorm** out) {
+  if (!out || dim <= 0 || dim > 1024) return fail(nullptr, AMENV_ERR_INVALID, "amenv_obsnorm_create: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(nullptr, AMENV_ERR_NO_DEVICE, "amenv_obsnorm_create: no such HIP device");
+  amenv_obsnorm* h = new (std::nothrow) amenv_obsnorm();
+  if (!h) return AMENV_ERR_ALLOC;
+  h->dim = dim; h->device = device;
+  DeviceGuard g(device);
+  if (hipMalloc((void**)&h->buf, sizeof(double) * obsnorm_words(dim)) != hipSuccess) { delete h; return fail(nullptr, AMENV_ERR_ALLOC, "amenv_obsnorm_create: hipMalloc failed"); }
+  std::string zero_one(sizeof(double) * obsnorm_words(dim), '\0');
+  double* init = reinterpret_cast<double*>(&zero_one[0]);
+  for (int j = 0; j < dim; j++) init[dim + j] = 1.0;   // var = 1
+  init[2 * dim] = 1e-4;                                 // count = epsilon (sb3 RunningMeanStd default)
+  if (hipMemcpy(h->buf, init, zero_one.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(h->buf); delete h; return fail(nullptr, AMENV_ERR_HIP, "amenv_obsnorm_create: init copy failed"); }
+  *out = h;
+  return AMENV_OK;
+}
+
+int amenv_obsnorm_destroy(amenv_obsnorm* h) {
+  if (!h) return AMENV_OK;
+  { DeviceGuard g(h->device); if (h->buf) (void)hipFree(h->buf); }
+  delete h;
+  return AMENV_OK;
+}
+
+int amenv_obsnorm_update(amenv_obsnorm* h, const float* obs, int64_t n, void* stream) {
+  if (!h || !obs || n <= 0) return AMENV_ERR_INVALID;
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int d = h->dim, bs = 256;
+  const long long n_elems = (long long)n * d;
+  long long blocks = (n_elems + bs - 1) / bs;
+  if (blocks > 1024) blocks = 1024;
+  long long stride = blocks * bs;
+  stride = ((stride + d - 1) / d) * d;             // multiple of d: a thread stays on one column
+  blocks = (stride + bs - 1) / bs;
+  hipLaunchKernelGGL(obsnorm_sum_kernel, dim3((unsigned)blocks), dim3(bs), sizeof(double) * 2 * d, s, obs, n_elems, d, stride, h->buf);
+  hipLaunchKernelGGL(obsnorm_merge_kernel, dim3(1), dim3(((d + 63) / 64) * 64), 0, s, h->buf, d, double(n));
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+int amenv_obsnorm_apply(amenv_obsnorm* h, const float* in, float* out, int64_t n, float clip, double eps, void* stream) {
+  if (!h || !in || !out || n <= 0) return AMENV_ERR_INVALID;
+  DeviceGuard g(h->device);
+  const int d = h->dim, bs = 256;
+  const long long n_elems = (long long)n * d;
+  long long blocks = (n_elems + bs - 1) / bs;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(obsnorm_apply_kernel, dim3((unsigned)blocks), dim3(bs), sizeof(float) * 2 * d, (hipStream_t)stream, in, out, n_elems, d, (const double*)h->buf, clip, eps);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+int amenv_obsnorm_get(amenv_obsnorm* h, double* mean, double* var, double* count, void* stream) {
+  if (!h || !mean || !var || !count) return AMENV_ERR_INVALID;
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int d = h->dim;
+  if (hipMemcpyAsync(mean, h->buf, sizeof(double) * d, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(var, h->buf + d, sizeof(double) * d, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(count, h->buf + 2 * d, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return AMENV_ERR_HIP;
+  return AMENV_OK;
+}
+
+int amenv_obsnorm_set(amenv_obsnorm* h, const double* mean, const double* var, double count, void* stream) {
+  if (!h || !mean || !var) return AMENV_ERR_INVALID;
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int d = h->dim;
+  if (hipMemcpyAsync(h->buf, mean, sizeof(double) * d, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(h->buf + d, var, sizeof(double) * d, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(h->buf + 2 * d, &count, sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return AMENV_ERR_HIP;
   return AMENV_OK;
 }
 
