@@ -549,7 +549,7 @@ int amenv_obsnorm_apply(amenv_obsnorm* h, const float* in, float* out, int64_t n
   const long long n_elems = (long long)n * d;
   long long blocks = (n_elems + bs - 1) / bs;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(obsnorm_apply_kernel, dim3((unsigned)blocks), dim3(bs), sizeof(float) * 2 * d, (hipStream_t)stream, in, out, n_elems, d, (const double*)h->buf, clip, eps);
+  hipLaunchKernelGGL(obsnorm_apply_kernel, dim3((unsigned)blocks), dim3(bs), sizeof(double) * 2 * d, (hipStream_t)stream, in, out, n_elems, d, (const double*)h->buf, clip, eps);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

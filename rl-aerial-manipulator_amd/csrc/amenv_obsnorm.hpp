@@ -55,13 +55,15 @@ __global__ void obsnorm_merge_kernel(double* __restrict__ buf, int d, double bat
 // VecNormalize.normalize_obs: clip((obs - mean) / sqrt(var + eps), -clip, clip); in place allowed.
 __global__ __launch_bounds__(256) void obsnorm_apply_kernel(const float* __restrict__ in, float* __restrict__ out, long long n_elems, int d,
                                                             const double* __restrict__ buf, float clip, double eps) {
-  extern __shared__ float lds_ms[];  // [2d]: mean, 1/sqrt(var+eps)
-  for (int j = threadIdx.x; j < d; j += blockDim.x) { lds_ms[j] = float(buf[j]); lds_ms[d + j] = float(1.0 / sqrt(buf[d + j] + eps)); }
+  // mean and 1/sigma stay fp64: a nearly constant column (quaternion w ~ 1, var ~ 1e-7) has 1/sigma ~ 3e3, which would
+  // amplify an fp32-rounded mean into the 1e-4 range
+  extern __shared__ double lds_md[];  // [2d]: mean, 1/sqrt(var+eps)
+  for (int j = threadIdx.x; j < d; j += blockDim.x) { lds_md[j] = buf[j]; lds_md[d + j] = 1.0 / sqrt(buf[d + j] + eps); }
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_elems; e += stride) {
     const int col = int(e % d);
-    float v = (in[e] - lds_ms[col]) * lds_ms[d + col];
+    float v = float((double(in[e]) - lds_md[col]) * lds_md[d + col]);
     v = v < -clip ? -clip : (v > clip ? clip : v);
     out[e] = v;
   }
