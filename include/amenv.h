@@ -81,14 +81,20 @@ typedef struct amenv_vehicle {
   double t_min[AMENV_MAX_ROTORS];     /* per-rotor thrust floor (params.py:19, minF/4) */
   double t_max[AMENV_MAX_ROTORS];     /* per-rotor thrust cap   (params.py:20, maxF/4) */
   double moment_scale;   /* M = a[1:4]*moment_scale, evaluated in fp32 (rl_env_scaledObs.py:126: 0.1) */
-  /* arm (n_joints = 3) parameters; ignored for n_joints = 0.  See DESIGN.md "arm". */
-  double joint_origin[AMENV_MAX_JOINTS * 3]; /* joint frame origin in parent link frame */
-  double joint_axis[AMENV_MAX_JOINTS * 3];   /* unit axis in the child frame */
-  double link_mass[AMENV_MAX_JOINTS];
+  /* Arm (n_joints = 3): serial chain of revolute joints hanging from the base body; ignored for n_joints = 0.
+   * With an arm, `mass` is the TOTAL mass (action scaling F = a0*mass*g), the base body's own mass is
+   * mass - sum(link_mass), `inertia` is the base body's inertia about ITS CoM = the body-frame origin.
+   * Parameters from Manipulator/src/manipulator_description/sdf/manipulator.sdf via tools/arm_params.py;
+   * the joint servo model is this build's (no reference dynamics exist): DESIGN.md "arm". */
+  double joint_origin[AMENV_MAX_JOINTS * 3]; /* joint k origin in its parent's frame (joint 1: body frame), :99,159,233 */
+  double joint_axis[AMENV_MAX_JOINTS * 3];   /* unit axis (same in parent and child frame), :103,163,237 */
+  double link_mass[AMENV_MAX_JOINTS];        /* :131,191,265 (+ closed gripper folded into link 3) */
   double link_com[AMENV_MAX_JOINTS * 3];     /* link CoM in its own frame */
-  double link_inertia[AMENV_MAX_JOINTS * 9]; /* about the link CoM, link frame */
-  double joint_kp, joint_kd, joint_tau_max, joint_damping;
-  double joint_limit[AMENV_MAX_JOINTS * 2];
+  double link_inertia[AMENV_MAX_JOINTS * 9]; /* about the link CoM, link frame, row-major symmetric */
+  double joint_kp, joint_kd;                 /* servo: thdd = clamp(kp*(cmd - th) - kd*thd, +-joint_acc_max) */
+  double joint_acc_max;                      /* rad/s^2 (manipulator_moveit/config/joint_limits.yaml: 8) */
+  double joint_reserved;
+  double joint_limit[AMENV_MAX_JOINTS * 2];  /* [lower, upper] rad: action -1..1 maps onto it, :105-106,165-166,239-240 */
 } amenv_vehicle;
 
 /* Task constants that the reference keeps as literals in rl_env_scaledObs.py. */
@@ -132,7 +138,7 @@ enum amenv_float_field {
   AMENV_F_LAST_DISTANCE,                           /* :76 ; < 0 encodes None          */
   AMENV_F_EP_RETURN,                               /* Monitor-style running return    */
   AMENV_F_WP0                                      /* waypoints: WP0 + 3*k + {0,1,2}  */
-  /* with n_joints = 3: joint angle, rate, target follow the waypoints (see amenv_state_dims) */
+  /* with n_joints = 3: joint angles (3) then joint rates (3) follow the waypoints: WP0 + 3*K + {0..5} */
 };
 enum amenv_int_field {
   AMENV_I_STEP = 0,   /* current_step (:55)                                         */

@@ -197,11 +197,158 @@ void orc_dynamics_step(const amenv_config* cfg, double* s, const float* action, 
   s[6] /= nq; s[7] /= nq; s[8] /= nq; s[9] /= nq;
 }
 
+
+/* ------------------------------------------------------------------------------------
+ * Hexacopter + 3-joint arm (BASELINE config 3).  NO reference dynamics exist for it (the reference simulates it in
+ * Gazebo): this is the fp64 statement of the model specified in DESIGN.md "arm"; parity unpinned, validated by
+ * invariants (tests/test_arm_cpu.py: momentum conservation, rigid limits, locked-arm = composite rigid body).
+ *   state  s[19] = [p(3) world, v(3) world, q(4), w(3) body, th(3), thd(3)]
+ *   joints : acceleration-limited position servos  thdd = clamp(kp (cmd - th) - kd thd, +-amax)
+ *   base   : exact rigid multibody reaction (Newton-Euler summed over base + links about the body origin O)
+ * ---------------------------------------------------------------------------------- */
+static void cross3(const double* a, const double* b, double* c) { c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0]; }
+static void matvec3(const double* M, const double* x, double* y) { for (int i = 0; i < 3; i++) y[i] = M[3 * i] * x[0] + M[3 * i + 1] * x[1] + M[3 * i + 2] * x[2]; }
+static void matmul3(const double* A, const double* B, double* C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double t = 0; for (int k = 0; k < 3; k++) t += A[3 * i + k] * B[3 * k + j]; C[3 * i + j] = t; } }
+static void rodrigues(const double* a, double th, double* R) { /* rotation by th about unit axis a */
+  const double c = cos(th), s_ = sin(th), t = 1 - c;
+  R[0] = c + a[0] * a[0] * t;        R[1] = a[0] * a[1] * t - a[2] * s_; R[2] = a[0] * a[2] * t + a[1] * s_;
+  R[3] = a[1] * a[0] * t + a[2] * s_; R[4] = c + a[1] * a[1] * t;        R[5] = a[1] * a[2] * t - a[0] * s_;
+  R[6] = a[2] * a[0] * t - a[1] * s_; R[7] = a[2] * a[1] * t + a[0] * s_; R[8] = c + a[2] * a[2] * t;
+}
+
+void orc_arm_rhs(const amenv_config* cfg, const double* s, double F, const double* M, const double* th_cmd, double* d) {
+  const amenv_vehicle* v = &cfg->vehicle;
+  const int nj = v->n_joints;
+  const double* om = &s[10]; const double* th = &s[13]; const double* thd = &s[16];
+  /* rotation of the normalised quaternion; body->world is its transpose (same convention as state_dot above) */
+  const double n2 = s[6] * s[6] + s[7] * s[7] + s[8] * s[8] + s[9] * s[9], nr = sqrt(n2);
+  const double qw = s[6] / nr, qx = s[7] / nr, qy = s[8] / nr, qz = s[9] / nr;
+  const double Rq[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                        2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                        2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+  const double gb[3] = {-v->g * Rq[2], -v->g * Rq[5], -v->g * Rq[8]};     /* gravity in body components: Rq (0,0,-g) */
+  double thdd[AMENV_MAX_JOINTS];
+  for (int k = 0; k < nj; k++) {
+    double a = v->joint_kp * (th_cmd[k] - th[k]) - v->joint_kd * thd[k];
+    thdd[k] = a > v->joint_acc_max ? v->joint_acc_max : (a < -v->joint_acc_max ? -v->joint_acc_max : a);
+  }
+  double m_links = 0; for (int k = 0; k < nj; k++) m_links += v->link_mass[k];
+  const double m0 = v->mass - m_links, mtot = v->mass;
+  /* accumulators: S = sum m r, I_O, bias force fb, bias moment nb */
+  double S[3] = {0, 0, 0}, IO[9], fb[3] = {0, 0, 0}, nb[3] = {0, 0, 0};
+  memcpy(IO, v->inertia, sizeof(IO));                                      /* base: r = 0, J = I0 */
+  { double Jw[3], c[3]; matvec3(v->inertia, om, Jw); cross3(om, Jw, c); for (int i = 0; i < 3; i++) nb[i] += c[i]; }   /* Omega x J Omega */
+  (void)m0;
+  /* chain kinematics relative to the body frame */
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0}, w[3] = {0, 0, 0}, al[3] = {0, 0, 0}, pd[3] = {0, 0, 0}, pdd[3] = {0, 0, 0};
+  for (int k = 0; k < nj; k++) {
+    const double* o = &v->joint_origin[3 * k]; const double* ax = &v->joint_axis[3 * k];
+    double Ro[3], t1[3], t2[3];
+    matvec3(R, o, Ro);                                                     /* joint origin offset in body components */
+    /* origin of frame k: p += R_{k-1} o ; its velocity / acceleration use the PARENT's w, alpha */
+    cross3(w, Ro, t1); for (int i = 0; i < 3; i++) pd[i] += t1[i];
+    cross3(al, Ro, t1); double wxRo[3]; cross3(w, Ro, wxRo); cross3(w, wxRo, t2);
+    for (int i = 0; i < 3; i++) { pdd[i] += t1[i] + t2[i]; p[i] += Ro[i]; }
+    double z[3]; matvec3(R, ax, z);                                        /* joint axis in body components */
+    double wxz[3]; cross3(w, z, wxz);
+    for (int i = 0; i < 3; i++) { al[i] += z[i] * thdd[k] + wxz[i] * thd[k]; }   /* alpha_k = alpha_{k-1} + z thdd + (w_{k-1} x z) thd */
+    for (int i = 0; i < 3; i++) w[i] += z[i] * thd[k];                     /* w_k */
+    double Rj[9], Rn[9]; rodrigues(ax, th[k], Rj); matmul3(R, Rj, Rn); memcpy(R, Rn, sizeof(R));
+    /* link k centre of mass */
+    double Rc[3], r[3], u[3], a_[3];
+    matvec3(R, &v->link_com[3 * k], Rc);
+    cross3(w, Rc, t1); cross3(al, Rc, t2); double wxt1[3]; cross3(w, t1, wxt1);
+    for (int i = 0; i < 3; i++) { r[i] = p[i] + Rc[i]; u[i] = pd[i] + t1[i]; a_[i] = pdd[i] + t2[i] + wxt1[i]; }
+    /* inertia in body components: J = R I R^T */
+    double RI[9], Rt[9], J[9];
+    matmul3(R, &v->link_inertia[9 * k], RI);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+    matmul3(RI, Rt, J);
+    const double m = v->link_mass[k];
+    /* bias acceleration of the CoM: w x (w x r) + 2 w x u + a_rel (with the base's angular velocity om) */
+    double oxr[3], oxoxr[3], oxu[3], ab[3];
+    cross3(om, r, oxr); cross3(om, oxr, oxoxr); cross3(om, u, oxu);
+    for (int i = 0; i < 3; i++) ab[i] = oxoxr[i] + 2 * oxu[i] + a_[i];
+    double rxab[3]; cross3(r, ab, rxab);
+    /* angular part: J (alpha + om x w) + Omega x (J Omega), Omega = om + w */
+    double oxw[3], aa[3], Jaa[3], Om[3], JOm[3], OxJO[3];
+    cross3(om, w, oxw); for (int i = 0; i < 3; i++) { aa[i] = al[i] + oxw[i]; Om[i] = om[i] + w[i]; }
+    matvec3(J, aa, Jaa); matvec3(J, Om, JOm); cross3(Om, JOm, OxJO);
+    const double r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    for (int i = 0; i < 3; i++) {
+      S[i] += m * r[i]; fb[i] += m * ab[i]; nb[i] += m * rxab[i] + Jaa[i] + OxJO[i];
+      for (int j = 0; j < 3; j++) IO[3 * i + j] += J[3 * i + j] + m * ((i == j ? r2 : 0.0) - r[i] * r[j]);
+    }
+  }
+  /* external wrench about O in body components: rotor thrust + moments, gravity at every CoM */
+  double f[3], n[3], Sxg[3];
+  cross3(S, gb, Sxg);
+  for (int i = 0; i < 3; i++) { f[i] = mtot * gb[i] - fb[i]; n[i] = M[i] + Sxg[i] - nb[i]; }
+  f[2] += F;
+  /* [mtot 1, -[S]x; [S]x, I_O] [A; wd] = [f; n]  ->  I_c wd = n - S x f / mtot,  I_c = I_O - (|S|^2 1 - S S^T)/mtot */
+  double Ic[9], Sxf[3], rhs[3];
+  const double S2 = S[0] * S[0] + S[1] * S[1] + S[2] * S[2];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ic[3 * i + j] = IO[3 * i + j] - ((i == j ? S2 : 0.0) - S[i] * S[j]) / mtot;
+  cross3(S, f, Sxf);
+  for (int i = 0; i < 3; i++) rhs[i] = n[i] - Sxf[i] / mtot;
+  double Ici[9], wd[3], A[3], Sxwd[3];
+  inv3(Ic, Ici); matvec3(Ici, rhs, wd);
+  cross3(S, wd, Sxwd);
+  for (int i = 0; i < 3; i++) A[i] = (f[i] + Sxwd[i]) / mtot;
+  /* derivatives */
+  d[0] = s[3]; d[1] = s[4]; d[2] = s[5];
+  for (int i = 0; i < 3; i++) d[3 + i] = Rq[0 + i] * A[0] + Rq[3 + i] * A[1] + Rq[6 + i] * A[2];   /* v' = Rq^T A */
+  const double pq = om[0], qq = om[1], rq = om[2], qe = 1.0 - n2;
+  d[6] = -0.5 * (-pq * s[7] - qq * s[8] - rq * s[9]) + 2.0 * qe * s[6];
+  d[7] = -0.5 * (pq * s[6] - rq * s[8] + qq * s[9]) + 2.0 * qe * s[7];
+  d[8] = -0.5 * (qq * s[6] + rq * s[7] - pq * s[9]) + 2.0 * qe * s[8];
+  d[9] = -0.5 * (rq * s[6] - qq * s[7] + pq * s[8]) + 2.0 * qe * s[9];
+  d[10] = wd[0]; d[11] = wd[1]; d[12] = wd[2];
+  for (int k = 0; k < 3; k++) { d[13 + k] = k < nj ? thd[k] : 0.0; d[16 + k] = k < nj ? thdd[k] : 0.0; }
+}
+
+/* One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states. */
+void orc_arm_dynamics_step(const amenv_config* cfg, double* s, const float* action, double* wrench_out) {
+  const amenv_vehicle* v = &cfg->vehicle;
+  const int n = v->n_rotors;
+  double u[4], T[AMENV_MAX_ROTORS];
+  scale_action(v, action, u);
+  double F = 0, M[3] = {0, 0, 0};
+  for (int r = 0; r < n; r++) {
+    double t = 0; for (int j = 0; j < 4; j++) t += v->alloc[r * 4 + j] * u[j];
+    t = fmax(fmin(t, v->t_max[r]), v->t_min[r]); T[r] = t; F += t;
+  }
+  for (int i = 0; i < 3; i++) for (int r = 0; r < n; r++) M[i] += v->mix[(1 + i) * n + r] * T[r];
+  double cmd[3];
+  for (int k = 0; k < 3; k++) {   /* action -1..1 -> joint range; formed in fp32 like the other action scalings */
+    const float lo = (float)v->joint_limit[2 * k], hi = (float)v->joint_limit[2 * k + 1];
+    volatile float half = 0.5f * (hi - lo), mid = 0.5f * (hi + lo);
+    volatile float c = fmaf(action[4 + k], half, mid);
+    cmd[k] = (double)c;
+  }
+  if (wrench_out) { wrench_out[0] = F; wrench_out[1] = M[0]; wrench_out[2] = M[1]; wrench_out[3] = M[2]; wrench_out[4] = cmd[0]; wrench_out[5] = cmd[1]; wrench_out[6] = cmd[2]; }
+  const int ns = cfg->task.rk4_substeps > 0 ? cfg->task.rk4_substeps : 1;
+  const double h = cfg->task.dt / ns;
+  for (int it = 0; it < ns; it++) {
+    double k1[19], k2[19], k3[19], k4[19], y[19];
+    orc_arm_rhs(cfg, s, F, M, cmd, k1);
+    for (int i = 0; i < 19; i++) y[i] = s[i] + 0.5 * h * k1[i];
+    orc_arm_rhs(cfg, y, F, M, cmd, k2);
+    for (int i = 0; i < 19; i++) y[i] = s[i] + 0.5 * h * k2[i];
+    orc_arm_rhs(cfg, y, F, M, cmd, k3);
+    for (int i = 0; i < 19; i++) y[i] = s[i] + h * k3[i];
+    orc_arm_rhs(cfg, y, F, M, cmd, k4);
+    for (int i = 0; i < 19; i++) s[i] += h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+  }
+  const double nq = sqrt(s[6] * s[6] + s[7] * s[7] + s[8] * s[8] + s[9] * s[9]);
+  s[6] /= nq; s[7] /= nq; s[8] /= nq; s[9] /= nq;
+}
+
 /* ------------------------------------------------------------------------------------
  * Environment: v2/rl_env_scaledObs.py
  * ---------------------------------------------------------------------------------- */
 typedef struct {
-  double s[13];
+  double s[19];   /* 13 rigid-body states (+ 3 joint angles + 3 joint rates with an arm) */
   double wp[AMENV_MAX_WAYPOINTS][3];
   double final_yaw, last_distance, ep_return;
   int step, counter, wp_index, fwr, counter_activated, episode;
@@ -210,6 +357,7 @@ typedef struct {
 
 static void load_env(const amenv_config* cfg, int n, const double* f, const int32_t* is, int i, env_t* e) {
   for (int k = 0; k < 13; k++) e->s[k] = f[(size_t)k * n + i];
+  for (int k = 0; k < 6; k++) e->s[13 + k] = cfg->vehicle.n_joints ? f[(size_t)(AMENV_F_WP0 + 3 * cfg->task.num_waypoints + k) * n + i] : 0.0;
   e->final_yaw = f[(size_t)AMENV_F_FINAL_YAW * n + i];
   e->last_distance = f[(size_t)AMENV_F_LAST_DISTANCE * n + i];
   e->ep_return = f[(size_t)AMENV_F_EP_RETURN * n + i];
@@ -224,6 +372,7 @@ static void load_env(const amenv_config* cfg, int n, const double* f, const int3
 
 static void store_env(const amenv_config* cfg, int n, double* f, int32_t* is, int i, const env_t* e) {
   for (int k = 0; k < 13; k++) f[(size_t)k * n + i] = e->s[k];
+  if (cfg->vehicle.n_joints) for (int k = 0; k < 6; k++) f[(size_t)(AMENV_F_WP0 + 3 * cfg->task.num_waypoints + k) * n + i] = e->s[13 + k];
   f[(size_t)AMENV_F_FINAL_YAW * n + i] = e->final_yaw;
   f[(size_t)AMENV_F_LAST_DISTANCE * n + i] = e->last_distance;
   f[(size_t)AMENV_F_EP_RETURN * n + i] = e->ep_return;
@@ -236,7 +385,9 @@ static void store_env(const amenv_config* cfg, int n, double* f, int32_t* is, in
 }
 
 static int is_v1(const amenv_config* cfg) { return cfg->task.variant == AMENV_TASK_V1_SCALED17 || cfg->task.variant == AMENV_TASK_V1_RAW17; }
-static int obs_dim(const amenv_config* cfg) { return is_v1(cfg) ? 17 : 20; }
+static int obs_dim(const amenv_config* cfg) { return is_v1(cfg) ? 17 : 20 + 2 * cfg->vehicle.n_joints; }
+static int act_dim(const amenv_config* cfg) { return 4 + cfg->vehicle.n_joints; }
+int orc_act_dim(const amenv_config* cfg) { return act_dim(cfg); }
 int orc_obs_dim(const amenv_config* cfg) { return obs_dim(cfg); }
 static int env_K(const amenv_config* cfg, const env_t* e) { return e->k_env ? e->k_env : cfg->task.num_waypoints; }
 
@@ -271,6 +422,10 @@ static void observe_v2(const amenv_config* cfg, const env_t* e, float* obs) {
     obs[16 + c] = (float)(rel / 2.0);
   }
   obs[19] = (float)(e->final_yaw / PI_D);                                  /* :118 */
+  for (int k = 0; k < cfg->vehicle.n_joints; k++) {                        /* arm (this build's extension): joint angle / pi, rate / 5 */
+    obs[20 + k] = (float)(e->s[13 + k] / PI_D);
+    obs[20 + cfg->vehicle.n_joints + k] = (float)(e->s[16 + k] / 5.0);
+  }
 }
 
 static void observe(const amenv_config* cfg, const env_t* e, float* obs) {
@@ -294,11 +449,12 @@ static double norm3(const double* a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a
  * Returns info bits; *reward_out the f64 reward.  No auto-reset here. */
 static uint32_t env_step_v2(const amenv_config* cfg, env_t* e, const float* action, double* reward_out) {
   const int K = cfg->task.num_waypoints;
-  orc_dynamics_step(cfg, e->s, action, NULL);                              /* :125-131 */
+  if (cfg->vehicle.n_joints) orc_arm_dynamics_step(cfg, e->s, action, NULL);
+  else orc_dynamics_step(cfg, e->s, action, NULL);                         /* :125-131 */
 
   uint32_t bits = 0;
   if (cfg->flags & AMENV_FLAG_NAN_GUARD) {   /* deviation from the reference, documented in DESIGN.md */
-    int bad = 0; for (int k = 0; k < 13; k++) bad |= !isfinite(e->s[k]);
+    int bad = 0; for (int k = 0; k < 13 + 2 * cfg->vehicle.n_joints; k++) bad |= !isfinite(e->s[k]);
     if (bad) {
       bits = AMENV_INFO_TERMINATED | AMENV_INFO_NONFINITE;
       if (e->step >= cfg->task.max_episode_steps) bits |= AMENV_INFO_TRUNCATED;
@@ -567,7 +723,7 @@ int orc_observe(const amenv_config* cfg, const double* fstate, const int32_t* is
 int orc_step(const amenv_config* cfg, double* fstate, int32_t* istate, const float* actions, float* obs, double* reward,
              uint8_t* done, uint32_t* info_bits, float* terminal_obs, float* ep_return, int32_t* ep_len, int nthreads) {
   const int n = cfg->num_envs;
-  const int od = obs_dim(cfg), ad = 4;
+  const int od = obs_dim(cfg), ad = act_dim(cfg);
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(static) if (nthreads != 1)
@@ -601,9 +757,9 @@ int orc_rollout(const amenv_config* cfg, double* fstate, int32_t* istate, int T,
 #endif
   for (int i = 0; i < n; i++) {
     env_t e; load_env(cfg, n, fstate, istate, i, &e);
-    double acc = 0; float o[20];
+    double acc = 0; float o[32];
     for (int t = 0; t < T; t++) {
-      double r; uint32_t bits = env_step(cfg, &e, actions + ((size_t)t * n + i) * 4, &r);
+      double r; uint32_t bits = env_step(cfg, &e, actions + ((size_t)t * n + i) * act_dim(cfg), &r);
       e.ep_return += r; acc += r;
       observe(cfg, &e, o);
       if ((bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) && (cfg->flags & AMENV_FLAG_AUTO_RESET)) env_reset(cfg, cfg->env_id_offset + i, &e);

@@ -33,7 +33,7 @@ class Vehicle(C.Structure):
         ("joint_origin", C.c_double * (MAX_JOINTS * 3)), ("joint_axis", C.c_double * (MAX_JOINTS * 3)),
         ("link_mass", C.c_double * MAX_JOINTS), ("link_com", C.c_double * (MAX_JOINTS * 3)),
         ("link_inertia", C.c_double * (MAX_JOINTS * 9)),
-        ("joint_kp", C.c_double), ("joint_kd", C.c_double), ("joint_tau_max", C.c_double), ("joint_damping", C.c_double),
+        ("joint_kp", C.c_double), ("joint_kd", C.c_double), ("joint_acc_max", C.c_double), ("joint_reserved", C.c_double),
         ("joint_limit", C.c_double * (MAX_JOINTS * 2)),
     ]
 
@@ -76,6 +76,9 @@ def lib():
         L.orc_set_num_waypoints.argtypes = [C.POINTER(Config), C.c_int32]
         L.orc_n_float_fields.argtypes = [C.POINTER(Config)]
         L.orc_obs_dim.argtypes = [C.POINTER(Config)]
+        L.orc_act_dim.argtypes = [C.POINTER(Config)]
+        L.orc_arm_rhs.argtypes = [C.POINTER(Config), P, C.c_double, P, P, P]
+        L.orc_arm_dynamics_step.argtypes = [C.POINTER(Config), P, P, P]
         L.orc_dynamics_step.argtypes = [C.POINTER(Config), P, P, P]
         L.orc_reset.argtypes = [C.POINTER(Config), P, P, P, P]
         L.orc_observe.argtypes = [C.POINTER(Config), P, P, P]
@@ -114,7 +117,7 @@ class OracleEnv:
         self.nf = lib().orc_n_float_fields(C.byref(cfg))
         self.fstate = np.zeros((self.nf, self.n), np.float64)
         self.istate = np.zeros((I_NFIELDS, self.n), np.int32)
-        self.obs_dim, self.act_dim = lib().orc_obs_dim(C.byref(cfg)), 4
+        self.obs_dim, self.act_dim = lib().orc_obs_dim(C.byref(cfg)), lib().orc_act_dim(C.byref(cfg))
 
     def reset(self, mask=None):
         obs = np.zeros((self.n, self.obs_dim), np.float32)
@@ -168,6 +171,19 @@ def dynamics_step(cfg, state13, action):
     wrench = np.zeros(8, np.float64)
     lib().orc_dynamics_step(C.byref(cfg), _p(s), _p(a), _p(wrench))
     return s, wrench
+
+
+def arm_rhs(cfg, s19, F, M, th_cmd):
+    s = np.ascontiguousarray(s19, np.float64); M = np.ascontiguousarray(M, np.float64); c = np.ascontiguousarray(th_cmd, np.float64)
+    d = np.zeros(19)
+    lib().orc_arm_rhs(C.byref(cfg), _p(s), float(F), _p(M), _p(c), _p(d))
+    return d
+
+
+def arm_dynamics_step(cfg, s19, action7):
+    s = np.array(s19, np.float64).copy(); a = np.ascontiguousarray(action7, np.float32); w = np.zeros(8)
+    lib().orc_arm_dynamics_step(C.byref(cfg), _p(s), _p(a), _p(w))
+    return s, w
 
 
 def philox(seed, gid, episode, block):

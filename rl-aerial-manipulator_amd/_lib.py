@@ -28,7 +28,7 @@ class Vehicle(C.Structure):
         ("joint_origin", C.c_double * (MAX_JOINTS * 3)), ("joint_axis", C.c_double * (MAX_JOINTS * 3)),
         ("link_mass", C.c_double * MAX_JOINTS), ("link_com", C.c_double * (MAX_JOINTS * 3)),
         ("link_inertia", C.c_double * (MAX_JOINTS * 9)),
-        ("joint_kp", C.c_double), ("joint_kd", C.c_double), ("joint_tau_max", C.c_double), ("joint_damping", C.c_double),
+        ("joint_kp", C.c_double), ("joint_kd", C.c_double), ("joint_acc_max", C.c_double), ("joint_reserved", C.c_double),
         ("joint_limit", C.c_double * (MAX_JOINTS * 2)),
     ]
 

@@ -146,6 +146,37 @@ bool vehicle_hexa(amenv_vehicle* v) {
   return true;
 }
 
+// BASELINE config 3: the hexacopter carrying the 3-joint arm (custom_hexa_arm/model.sdf:1741-1759 attaches
+// Manipulator/.../sdf/manipulator.sdf to base_link).  All numbers printed by tools/arm_params.py from those SDF files.
+// Parity unpinned (no reference dynamics); servo gains are this build's choice (DESIGN.md "arm").
+bool vehicle_hexa_arm(amenv_vehicle* v) {
+  if (!vehicle_hexa(v)) return false;
+  v->n_joints = 3;
+  v->mass = 3.2121;  // total: base body 2.8561 (27 hexacopter links + base_plate lump) + links 0.082 + 0.054 + 0.220
+  // base body inertia about its own CoM (= body-frame origin O; model-frame z = 0.038523)
+  const double I[9] = {4.4499781211e-02, 0, 8.3146456634e-06, 0, 4.4545235795e-02, 0, 8.3146456634e-06, 0, 7.7122576031e-02};
+  std::memcpy(v->inertia, I, sizeof(I));
+  if (!invert(3, I, v->inv_inertia)) return false;
+  const double jo[9] = {0.0094667379, -0.01, -0.103522586,   // joint_1 in the body frame (manipulator.sdf:99, rel. O)
+                        0.0, 0.0125, 0.0,                     // joint_2 in link 1 (:159)
+                        0.0, 0.0, -0.106};                    // joint_3 in link 2 (:233)
+  const double ja[9] = {0, 0, 1, 1, 0, 0, 1, 0, 0};          // axes z, x, x (:103,163,237)
+  const double lm[3] = {0.082, 0.054, 0.220};                // :131,191,265 (+ 2 x 0.02 closed gripper fingers in link 3)
+  const double lc[9] = {0, 0, 0, 0, 0, -0.052, 0.0058295455, -0.0054545455, -0.0822272727};
+  const double li[27] = {2.10193333e-05, 0, 0, 0, 2.31308333e-05, 0, 0, 0, 3.62781667e-05,
+                         1.980045e-04, 0, 0, 0, 2.266425e-04, 0, 0, 0, 3.4263e-05,
+                         8.2716818176e-04, 2.6844545455e-05, 5.7916022727e-05, 2.6844545455e-05, 8.5215807772e-04, -5.1327272727e-05,
+                         5.7916022727e-05, -5.1327272727e-05, 1.0384565341e-04};
+  std::memcpy(v->joint_origin, jo, sizeof(jo)); std::memcpy(v->joint_axis, ja, sizeof(ja));
+  std::memcpy(v->link_mass, lm, sizeof(lm)); std::memcpy(v->link_com, lc, sizeof(lc)); std::memcpy(v->link_inertia, li, sizeof(li));
+  v->joint_kp = 100.0; v->joint_kd = 20.0;   // critically damped position servo, 10 rad/s bandwidth (this build's choice)
+  v->joint_acc_max = 8.0;                    // manipulator_moveit/config/joint_limits.yaml:9-51
+  v->joint_reserved = 0.0;
+  const double lim[6] = {-3.14, 3.14, -1.57, 1.57, -1.57, 1.57};   // manipulator.sdf:105-106,165-166,239-240
+  std::memcpy(v->joint_limit, lim, sizeof(lim));
+  return true;
+}
+
 template <typename T, int NR>
 HotParams<T, NR> make_hot(const amenv& e) {
   const amenv_config& c = e.cfg;
@@ -179,7 +210,8 @@ ColdParams make_cold(const amenv& e) {
 }
 
 bool is_v1(const amenv_config* c) { return c->task.variant == AMENV_TASK_V1_SCALED17 || c->task.variant == AMENV_TASK_V1_RAW17; }
-int obs_dim_of(const amenv_config* c) { return is_v1(c) ? 17 : 20; }
+int obs_dim_of(const amenv_config* c) { return is_v1(c) ? 17 : 20 + 2 * c->vehicle.n_joints; }
+int act_dim_of(const amenv_config* c) { return kActDim + c->vehicle.n_joints; }
 
 int n_float_fields(const amenv_config* c) { return AMENV_F_WP0 + 3 * c->task.num_waypoints + 3 * c->vehicle.n_joints; }
 
@@ -280,7 +312,8 @@ int amenv_default_config(const char* vehicle_name, int32_t num_envs, amenv_confi
   bool ok;
   if (!std::strcmp(vehicle_name, "quad")) ok = vehicle_quad(&cfg->vehicle);
   else if (!std::strcmp(vehicle_name, "hexa")) ok = vehicle_hexa(&cfg->vehicle);
-  else return fail(nullptr, AMENV_ERR_INVALID, std::string("unknown vehicle '") + vehicle_name + "' (quad | hexa)");
+  else if (!std::strcmp(vehicle_name, "hexa_arm")) ok = vehicle_hexa_arm(&cfg->vehicle);
+  else return fail(nullptr, AMENV_ERR_INVALID, std::string("unknown vehicle '") + vehicle_name + "' (quad | hexa | hexa_arm)");
   if (!ok) return fail(nullptr, AMENV_ERR_INVALID, "singular vehicle matrices");
   fill_task_defaults(&cfg->task, 1);
   return AMENV_OK;
@@ -303,7 +336,7 @@ int amenv_config_set_task(amenv_config* cfg, int32_t variant) {
 int amenv_dims(const amenv_config* cfg, int32_t* obs_dim, int32_t* act_dim, int32_t* nff, int32_t* nif) {
   if (!cfg) return AMENV_ERR_INVALID;
   if (obs_dim) *obs_dim = obs_dim_of(cfg);
-  if (act_dim) *act_dim = kActDim;
+  if (act_dim) *act_dim = act_dim_of(cfg);
   if (nff) *nff = n_float_fields(cfg);
   if (nif) *nif = AMENV_I_NFIELDS;
   return AMENV_OK;

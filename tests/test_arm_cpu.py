@@ -1,0 +1,199 @@
+"""Physics checks of the hexacopter + 3-joint arm model (BASELINE config 3) on the CPU oracle.  No reference dynamics
+exist for this configuration (the reference simulates it in Gazebo), so instead of golden vectors the model is pinned
+by formulation-independent invariants:
+  - total linear and angular momentum (computed from positions/velocities only) are conserved without external wrench
+    while the joints move;
+  - arm locked  => identical to the rigid-body oracle run on the composite mass / CoM / inertia;
+  - link masses -> 0 => identical to the rigid hexacopter;
+  - hover thrust balances the total weight; the gravity moment of the offset arm CoM is what tilts it.
+"""
+import ctypes as C
+
+import numpy as np
+
+import rl_aerial_manipulator_amd as amd
+from oracle import oracle as O
+
+
+def arm_cfg(**over):
+    pc = amd._lib.default_config("hexa_arm", 1)
+    cfg = O.reference_quad_config(1, flags=0)
+    C.memmove(C.byref(cfg.vehicle), C.byref(pc.vehicle), C.sizeof(O.Vehicle))
+    for k, v in over.items():
+        setattr(cfg.vehicle, k, v)
+    return cfg
+
+
+def rot_q(q):  # rotation matrix of the normalised quaternion (body->world is its transpose in this model)
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def rodrigues(a, th):
+    a = np.asarray(a, float); K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def momenta(cfg, s):
+    """Total linear momentum and angular momentum about the world origin, from positions and velocities only."""
+    v = cfg.vehicle
+    Rwb = rot_q(s[6:10]).T                               # body -> world
+    om = s[10:13]
+    m_links = np.array(v.link_mass[:3]); m0 = v.mass - m_links.sum()
+    bodies = [(m0, np.zeros(3), np.zeros(3), np.array(v.inertia).reshape(3, 3), np.zeros(3))]  # (m, r, u, J_body, w_rel)
+    R = np.eye(3); p = np.zeros(3); pd = np.zeros(3); w = np.zeros(3)
+    for k in range(3):
+        o = np.array(v.joint_origin[3 * k:3 * k + 3]); ax = np.array(v.joint_axis[3 * k:3 * k + 3])
+        pd = pd + np.cross(w, R @ o); p = p + R @ o
+        w = w + (R @ ax) * s[16 + k]
+        R = R @ rodrigues(ax, s[13 + k])
+        c = R @ np.array(v.link_com[3 * k:3 * k + 3])
+        J = R @ np.array(v.link_inertia[9 * k:9 * k + 9]).reshape(3, 3) @ R.T
+        bodies.append((m_links[k], p + c, pd + np.cross(w, c), J, w.copy()))
+    P = np.zeros(3); Lw = np.zeros(3); mt = 0; xc = np.zeros(3)
+    for m, r, u, J, wr in bodies:
+        x = s[0:3] + Rwb @ r                                         # world position of the CoM
+        vel = s[3:6] + Rwb @ (np.cross(om, r) + u)                   # world velocity of the CoM
+        P += m * vel
+        Lw += np.cross(x, m * vel) + Rwb @ (J @ (om + wr))
+        mt += m; xc += m * x
+    return P, Lw, xc / mt
+
+
+def test_momentum_conservation_with_moving_joints():
+    cfg = arm_cfg(g=0.0)
+    rng = np.random.RandomState(0)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    s = np.concatenate([[0.3, -0.2, 1.5], [0.4, -0.1, 0.2], q, [0.5, -0.8, 0.3], [0.2, -0.4, 0.6], [0.0, 0.0, 0.0]])
+    P0, L0, _ = momenta(cfg, s)
+    a = np.array([0, 0, 0, 0, 0.9, -0.7, 0.8], np.float32)           # zero rotor wrench (t_min = 0 below), joints slewing
+    cfg.vehicle.t_min[:] = (C.c_double * 8)(*([0.0] * 8))
+    worst = 0.0; peak_rate = 0.0
+    for t in range(400):
+        s, w = O.arm_dynamics_step(cfg, s, a)
+        peak_rate = max(peak_rate, np.abs(s[16:19]).max())
+        assert w[0] == 0 and not w[1:4].any()
+        P, L, _ = momenta(cfg, s)
+        worst = max(worst, np.abs(P - P0).max() / np.abs(P0).max(), np.abs(L - L0).max() / np.abs(L0).max())
+    assert peak_rate > 1.0 and np.abs(s[13:16] - [0.2, -0.4, 0.6]).max() > 0.5                 # the arm really moved
+    assert worst < 5e-9, worst                                                                 # RK4(5 ms) integration error only
+
+
+def test_momentum_rate_equals_external_wrench():
+    """dP/dt = F_world + m g,  dL/dt = x_O x F_world + R M + sum x_k x m_k g  (finite differences of the same momenta)."""
+    cfg = arm_cfg()
+    rng = np.random.RandomState(1)
+    for trial in range(5):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        s = np.concatenate([rng.uniform(-1, 1, 3), rng.normal(0, 0.5, 3), q, rng.normal(0, 1, 3), rng.uniform(-1, 1, 3), rng.normal(0, 1, 3)])
+        F, M, cmd = 25.0 + rng.normal(), rng.normal(0, 0.5, 3), rng.uniform(-1, 1, 3)
+        d = O.arm_rhs(cfg, s, F, M, cmd)
+        eps = 1e-6
+        Pp, Lp, _ = momenta(cfg, s + eps * d); Pm, Lm, _ = momenta(cfg, s - eps * d)
+        _, _, xc = momenta(cfg, s)
+        dP, dL = (Pp - Pm) / (2 * eps), (Lp - Lm) / (2 * eps)
+        Rwb = rot_q(s[6:10]).T
+        Fw = Rwb @ np.array([0, 0, F]); g = np.array([0, 0, -cfg.vehicle.g]); mt = cfg.vehicle.mass
+        # the quaternion constraint term 2(1-|q|^2)q vanishes for unit q, so the finite difference is exact to O(eps^2)
+        np.testing.assert_allclose(dP, Fw + mt * g, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(dL, np.cross(s[0:3], Fw) + Rwb @ M + np.cross(xc, mt * g), rtol=0, atol=1e-8)
+
+
+def test_massless_arm_is_the_rigid_hexacopter():
+    cfg = arm_cfg()
+    hexa = O.reference_quad_config(1, flags=0)
+    C.memmove(C.byref(hexa.vehicle), C.byref(amd._lib.default_config("hexa", 1).vehicle), C.sizeof(O.Vehicle))
+    for k in range(3):
+        cfg.vehicle.link_mass[k] = 1e-300
+        for j in range(9):
+            cfg.vehicle.link_inertia[9 * k + j] = 0.0
+    cfg.vehicle.mass = hexa.vehicle.mass
+    for j in range(9):
+        cfg.vehicle.inertia[j] = hexa.vehicle.inertia[j]; cfg.vehicle.inv_inertia[j] = hexa.vehicle.inv_inertia[j]
+    rng = np.random.RandomState(2)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    s13 = np.concatenate([[0, 0, 2.0], rng.normal(0, 1, 3), q, rng.normal(0, 1, 3)])
+    sa = np.concatenate([s13, [0.3, -0.2, 0.1], [0, 0, 0]]); sr = s13.copy()
+    for t in range(100):
+        a = rng.uniform([0.5, -0.3, -0.3, -0.3], [1.5, 0.3, 0.3, 0.3]).astype(np.float32)
+        sa, _ = O.arm_dynamics_step(cfg, sa, np.concatenate([a, [0.5, 0.5, -0.5]]).astype(np.float32))
+        sr, _ = O.dynamics_step(hexa, sr, a)
+        assert np.abs(sa[:13] - sr).max() < 1e-10
+
+
+def test_locked_arm_equals_composite_rigid_body():
+    cfg = arm_cfg(joint_kp=0.0, joint_kd=0.0)            # thdd = 0, joints stay where they are
+    th = np.array([0.4, -0.7, 0.9])
+    s0 = np.concatenate([[0, 0, 2.0], [0, 0, 0], [1, 0, 0, 0], [0, 0, 0], th, [0, 0, 0]])
+    _, _, xc0 = momenta(cfg, s0)
+    # composite inertia about the composite CoM in body axes, from the same kinematics helper
+    v = cfg.vehicle
+    m_links = np.array(v.link_mass[:3]); m0 = v.mass - m_links.sum()
+    R = np.eye(3); p = np.zeros(3); parts = [(m0, np.zeros(3), np.array(v.inertia).reshape(3, 3))]
+    for k in range(3):
+        p = p + R @ np.array(v.joint_origin[3 * k:3 * k + 3]); R = R @ rodrigues(v.joint_axis[3 * k:3 * k + 3], th[k])
+        parts.append((m_links[k], p + R @ np.array(v.link_com[3 * k:3 * k + 3]), R @ np.array(v.link_inertia[9 * k:9 * k + 9]).reshape(3, 3) @ R.T))
+    rc = sum(m * r for m, r, _ in parts) / v.mass
+    Ic = sum(J + m * (((r - rc) @ (r - rc)) * np.eye(3) - np.outer(r - rc, r - rc)) for m, r, J in parts)
+    rigid = O.reference_quad_config(1, flags=0)
+    C.memmove(C.byref(rigid.vehicle), C.byref(cfg.vehicle), C.sizeof(O.Vehicle))
+    rigid.vehicle.n_joints = 0
+    for j in range(9):
+        rigid.vehicle.inertia[j] = Ic.reshape(-1)[j]; rigid.vehicle.inv_inertia[j] = np.linalg.inv(Ic).reshape(-1)[j]
+    rng = np.random.RandomState(3)
+    sa = s0.copy(); sr = np.concatenate([xc0, s0[3:13]])
+    for t in range(150):
+        a = rng.uniform([0.8, -0.2, -0.2, -0.2], [1.2, 0.2, 0.2, 0.2]).astype(np.float32)
+        sa, w = O.arm_dynamics_step(cfg, sa, np.concatenate([a, [0, 0, 0]]).astype(np.float32))
+        # the rigid body sees the same thrust, and the rotor moments re-expressed about the composite CoM: M_c = M - rc x (0,0,F)
+        Rwb = rot_q(sr[6:10]).T
+        Mc = w[1:4] - np.cross(rc, [0, 0, w[0]])
+        sr = rigid_step(rigid, sr, w[0], Mc)
+        _, _, xc = momenta(cfg, sa)
+        assert np.abs(xc - sr[0:3]).max() < 2e-9 and np.abs(sa[6:13] - sr[6:13]).max() < 2e-9, t
+    assert np.allclose(sa[13:16], th) and not sa[16:19].any()
+
+
+def rigid_step(cfg, s, F, M):
+    """RK4 step of the rigid oracle RHS with an explicit wrench (bypasses the mixer)."""
+    import ctypes
+    lib = O.lib()
+    # state_dot is static in the oracle: integrate here with the same closed form (quadcopter.py:66-103)
+    v = cfg.vehicle
+    I = np.array(v.inertia).reshape(3, 3); J = np.array(v.inv_inertia).reshape(3, 3)
+
+    def f(y):
+        q = y[6:10]; n2 = q @ q; R = rot_q(q)
+        p_, q_, r_ = y[10:13]
+        acc = R.T @ np.array([0, 0, F]) / v.mass - np.array([0, 0, v.g])
+        Om = np.array([[0, -p_, -q_, -r_], [p_, 0, -r_, q_], [q_, r_, 0, -p_], [r_, -q_, p_, 0]])
+        qd = -0.5 * Om @ q + 2 * (1 - n2) * q
+        wd = J @ (M - np.cross(y[10:13], I @ y[10:13]))
+        return np.concatenate([y[3:6], acc, qd, wd])
+    h = cfg.task.dt
+    k1 = f(s); k2 = f(s + 0.5 * h * k1); k3 = f(s + 0.5 * h * k2); k4 = f(s + h * k3)
+    s = s + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    s[6:10] /= np.linalg.norm(s[6:10])
+    return s
+
+
+def test_hover_balance_and_servo_tracking():
+    cfg = arm_cfg()
+    v = cfg.vehicle
+    s = np.concatenate([[0, 0, 2.0], [0, 0, 0], [1, 0, 0, 0], [0, 0, 0], [0, 0, 0], [0, 0, 0]])
+    d = O.arm_rhs(cfg, s, v.mass * v.g, np.zeros(3), np.zeros(3))
+    _, _, xc = momenta(cfg, s)
+    a_com = d[3:6] + np.cross(d[10:13], xc - s[0:3])          # attitude = identity, w = 0: a_com = a_O + wd x r_c
+    assert np.abs(a_com).max() < 1e-12                        # thrust = total weight: the CoM does not accelerate ...
+    tau = np.cross(xc - s[0:3], [0, 0, -v.mass * v.g])        # ... but the arm's CoM offset gives a gravity moment about O
+    dL = O.arm_rhs(cfg, s, v.mass * v.g, -tau, np.zeros(3))   # cancel it with rotor moments: no angular acceleration either
+    assert np.abs(dL[10:13]).max() < 1e-10 and np.abs(d[10:13]).max() > 1e-3
+    # servo: commanded joint positions are reached (critically damped, acceleration-limited), within limits
+    a = np.array([1.0, 0, 0, 0, 0.5, -0.5, 1.0], np.float32)
+    for t in range(1200):
+        s, w = O.arm_dynamics_step(cfg, s, a)
+    np.testing.assert_allclose(s[13:16], w[4:7], atol=2e-3)
+    assert abs(w[4] - 1.57) < 1e-6 and abs(w[5] + 0.785) < 1e-6 and abs(w[6] - 1.57) < 1e-6
+    assert np.abs(s[16:19]).max() < 1e-2
