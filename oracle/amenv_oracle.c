@@ -109,7 +109,7 @@ void orc_set_num_waypoints(amenv_config* cfg, int32_t K) {
   }
 }
 
-static int n_float_fields(const amenv_config* cfg) { return AMENV_F_WP0 + 3 * cfg->task.num_waypoints + 3 * cfg->vehicle.n_joints; }
+static int n_float_fields(const amenv_config* cfg) { return AMENV_F_WP0 + 3 * cfg->task.num_waypoints + 2 * cfg->vehicle.n_joints; }
 int orc_n_float_fields(const amenv_config* cfg) { return n_float_fields(cfg); }
 
 /* ------------------------------------------------------------------------------------

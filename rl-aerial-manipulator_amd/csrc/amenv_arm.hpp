@@ -1,0 +1,201 @@
+// amenv_arm.hpp -- device dynamics of the hexacopter carrying the 3-joint arm (BASELINE config 3), DESIGN.md "arm".
+//
+// No reference code simulates this vehicle (the reference uses Gazebo for it): parity unpinned.  Parameters come from
+// the repo's SDF files (tools/arm_params.py).  Formulation (same as the fp64 oracle, written independently):
+//   state   [p(3) world, v(3) world, q(4), w(3) body, th(3), thd(3)]
+//   joints  acceleration-limited position servos: thdd = clamp(kp (cmd - th) - kd thd, +-amax)
+//   base    exact rigid multibody reaction.  With r_k, u_k, a_k the CoM position / velocity / acceleration of body k
+//           relative to the body frame, J_k its inertia in body axes, w_k / al_k its relative angular velocity /
+//           acceleration, Newton-Euler summed about the body origin O gives, for A = acceleration of O (body
+//           components) and wd = angular acceleration of the base,
+//             mtot A - S x wd = f      S = sum m_k r_k                     f = F_ext - sum m_k b_k
+//             S x A + I_O wd  = n      I_O = sum J_k + m_k(|r_k|^2 1 - r_k r_k^T)
+//                                       n = M_ext,O - sum [ m_k r_k x b_k + J_k(al_k + w x w_k) + W_k x (J_k W_k) ]
+//           b_k = w x (w x r_k) + 2 w x u_k + a_k,  W_k = w + w_k;  solved as  I_c wd = n - S x f / mtot  with the
+//           composite inertia about the system CoM  I_c = I_O - (|S|^2 1 - S S^T)/mtot,  then A = (f + S x wd)/mtot.
+#pragma once
+#include "amenv_model.hpp"
+
+namespace amenv_dev {
+
+template <typename T>
+struct ArmParams {
+  T jo[3][3];      // joint origin in the parent frame
+  T ja[3][3];      // joint axis (unit)
+  T lm[3];         // link mass
+  T lc[3][3];      // link CoM in the link frame
+  T li[3][6];      // link inertia about its CoM, link frame: xx xy xz yy yz zz
+  T kp, kd, amax;
+  T mtot, inv_mtot;
+  float mid[3], half[3];  // joint command = fmaf(action, half, mid), formed in fp32
+};
+
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator*(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename T> __device__ __forceinline__ V3<T> cross(V3<T> a, V3<T> b) {
+  return {fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))};
+}
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return dot3_(a.x, a.y, a.z, b.x, b.y, b.z); }
+
+template <typename T> struct M3 { T m[9]; };   // row-major
+template <typename T> __device__ __forceinline__ V3<T> mul(const M3<T>& A, V3<T> v) {
+  return {dot3_(A.m[0], A.m[1], A.m[2], v.x, v.y, v.z), dot3_(A.m[3], A.m[4], A.m[5], v.x, v.y, v.z), dot3_(A.m[6], A.m[7], A.m[8], v.x, v.y, v.z)};
+}
+template <typename T> __device__ __forceinline__ V3<T> mulT(const M3<T>& A, V3<T> v) {  // A^T v
+  return {dot3_(A.m[0], A.m[3], A.m[6], v.x, v.y, v.z), dot3_(A.m[1], A.m[4], A.m[7], v.x, v.y, v.z), dot3_(A.m[2], A.m[5], A.m[8], v.x, v.y, v.z)};
+}
+template <typename T> __device__ __forceinline__ M3<T> mul(const M3<T>& A, const M3<T>& B) {
+  M3<T> C;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C.m[3 * i + j] = dot3_(A.m[3 * i], A.m[3 * i + 1], A.m[3 * i + 2], B.m[j], B.m[3 + j], B.m[6 + j]);
+  return C;
+}
+__device__ __forceinline__ void sincos_(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }   // v_sin/v_cos, |x| <= pi
+__device__ __forceinline__ void sincos_(double x, double& s, double& c) { sincos(x, &s, &c); }
+
+template <typename T>
+__device__ __forceinline__ M3<T> rodrigues(V3<T> a, T th) {   // rotation by th about the unit axis a
+  T s, c;
+  sincos_(th, s, c);
+  const T t = T(1) - c;
+  M3<T> R;
+  R.m[0] = fma_(a.x * a.x, t, c);        R.m[1] = fma_(a.x * a.y, t, -(a.z * s)); R.m[2] = fma_(a.x * a.z, t, a.y * s);
+  R.m[3] = fma_(a.y * a.x, t, a.z * s);   R.m[4] = fma_(a.y * a.y, t, c);         R.m[5] = fma_(a.y * a.z, t, -(a.x * s));
+  R.m[6] = fma_(a.z * a.x, t, -(a.y * s)); R.m[7] = fma_(a.z * a.y, t, a.x * s);   R.m[8] = fma_(a.z * a.z, t, c);
+  return R;
+}
+
+// 19 derivatives of the arm vehicle.  y: state, F / M: rotor wrench after the mixer, cmd: joint position commands.
+template <typename T, typename PT>
+__device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
+  const V3<T> om{y[10], y[11], y[12]};
+  // rotation of the normalised quaternion (body -> world is its transpose, as in the rigid model)
+  const T n2 = fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9])));
+  const T in2 = rcp_(n2);
+  const T qw = y[6], qx = y[7], qy = y[8], qz = y[9];
+  const T two = T(2) * in2;
+  M3<T> Rq;
+  Rq.m[0] = fma_(-two, fma_(qy, qy, qz * qz), T(1)); Rq.m[1] = two * fma_(qx, qy, -(qw * qz)); Rq.m[2] = two * fma_(qx, qz, qw * qy);
+  Rq.m[3] = two * fma_(qx, qy, qw * qz); Rq.m[4] = fma_(-two, fma_(qx, qx, qz * qz), T(1)); Rq.m[5] = two * fma_(qy, qz, -(qw * qx));
+  Rq.m[6] = two * fma_(qx, qz, -(qw * qy)); Rq.m[7] = two * fma_(qy, qz, qw * qx); Rq.m[8] = fma_(-two, fma_(qx, qx, qy * qy), T(1));
+  const V3<T> gb{-P.g * Rq.m[2], -P.g * Rq.m[5], -P.g * Rq.m[8]};   // gravity in body components
+  T thdd[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) thdd[k] = clamp_(fma_(A.kp, cmd[k] - y[13 + k], -(A.kd * y[16 + k])), -A.amax, A.amax);
+  // base body: r = 0, J = I0
+  const M3<T> I0{{P.Ixx, P.Ixy, P.Ixz, P.Ixy, P.Iyy, P.Iyz, P.Ixz, P.Iyz, P.Izz}};
+  V3<T> S{T(0), T(0), T(0)}, fb{T(0), T(0), T(0)};
+  V3<T> nb = cross(om, mul(I0, om));
+  T IO[6] = {P.Ixx, P.Ixy, P.Ixz, P.Iyy, P.Iyz, P.Izz};               // xx xy xz yy yz zz
+  // chain kinematics relative to the body frame
+  M3<T> R{{T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}};
+  V3<T> p{T(0), T(0), T(0)}, pd = p, pdd = p, w = p, al = p;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const V3<T> o{A.jo[k][0], A.jo[k][1], A.jo[k][2]}, ax{A.ja[k][0], A.ja[k][1], A.ja[k][2]};
+    const V3<T> Ro = mul(R, o);
+    const V3<T> wRo = cross(w, Ro);
+    pd = pd + wRo;
+    pdd = pdd + cross(al, Ro) + cross(w, wRo);
+    p = p + Ro;
+    const V3<T> z = mul(R, ax);
+    al = al + thdd[k] * z + y[16 + k] * cross(w, z);
+    w = w + y[16 + k] * z;
+    R = mul(R, rodrigues(ax, y[13 + k]));
+    const V3<T> Rc = mul(R, V3<T>{A.lc[k][0], A.lc[k][1], A.lc[k][2]});
+    const V3<T> wRc = cross(w, Rc);
+    const V3<T> r = p + Rc, u = pd + wRc, a_ = pdd + cross(al, Rc) + cross(w, wRc);
+    const T m = A.lm[k];
+    const V3<T> b = cross(om, cross(om, r)) + T(2) * cross(om, u) + a_;
+    // rotational terms in the LINK frame: J x = R (I (R^T x))
+    const M3<T> Ik{{A.li[k][0], A.li[k][1], A.li[k][2], A.li[k][1], A.li[k][3], A.li[k][4], A.li[k][2], A.li[k][4], A.li[k][5]}};
+    const V3<T> aa = al + cross(om, w), Om = om + w;
+    const V3<T> Jaa = mul(R, mul(Ik, mulT(R, aa))), JOm = mul(R, mul(Ik, mulT(R, Om)));
+    S = S + m * r; fb = fb + m * b;
+    nb = nb + m * cross(r, b) + Jaa + cross(Om, JOm);
+    // I_O += R I R^T + m (|r|^2 1 - r r^T)   (symmetric: 6 entries)
+    const M3<T> RI = mul(R, Ik);
+    const T r2 = dot(r, r);
+    IO[0] += dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[0], R.m[1], R.m[2]) + m * (r2 - r.x * r.x);
+    IO[1] += dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[3], R.m[4], R.m[5]) - m * (r.x * r.y);
+    IO[2] += dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[6], R.m[7], R.m[8]) - m * (r.x * r.z);
+    IO[3] += dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[3], R.m[4], R.m[5]) + m * (r2 - r.y * r.y);
+    IO[4] += dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[6], R.m[7], R.m[8]) - m * (r.y * r.z);
+    IO[5] += dot3_(RI.m[6], RI.m[7], RI.m[8], R.m[6], R.m[7], R.m[8]) + m * (r2 - r.z * r.z);
+  }
+  // external wrench about O: rotor thrust / moments, gravity at every CoM
+  V3<T> f = A.mtot * gb - fb;
+  f.z += F;
+  const V3<T> n = M + cross(S, gb) - nb;
+  // I_c = I_O - (|S|^2 1 - S S^T)/mtot ; solve I_c wd = n - S x f / mtot by the adjugate
+  const T S2 = dot(S, S), im = A.inv_mtot;
+  const T a = IO[0] - (S2 - S.x * S.x) * im, bq = IO[1] + (S.x * S.y) * im, c = IO[2] + (S.x * S.z) * im;
+  const T dd = IO[3] - (S2 - S.y * S.y) * im, e = IO[4] + (S.y * S.z) * im, ff = IO[5] - (S2 - S.z * S.z) * im;
+  const V3<T> rhs = n - im * cross(S, f);
+  const T c00 = fma_(dd, ff, -(e * e)), c01 = fma_(c, e, -(bq * ff)), c02 = fma_(bq, e, -(c * dd));
+  const T c11 = fma_(a, ff, -(c * c)), c12 = fma_(bq, c, -(a * e)), c22 = fma_(a, dd, -(bq * bq));
+  const T idet = T(1) / fma_(a, c00, fma_(bq, c01, c * c02));
+  const V3<T> wd{idet * dot3_(c00, c01, c02, rhs.x, rhs.y, rhs.z), idet * dot3_(c01, c11, c12, rhs.x, rhs.y, rhs.z),
+                 idet * dot3_(c02, c12, c22, rhs.x, rhs.y, rhs.z)};
+  const V3<T> Aacc = im * (f + cross(S, wd));
+  const V3<T> vd = mulT(Rq, Aacc);                                   // world acceleration of O
+  d[0] = y[3]; d[1] = y[4]; d[2] = y[5];
+  d[3] = vd.x; d[4] = vd.y; d[5] = vd.z;
+  const T kq = fma_(T(-2), n2, T(2));
+  d[6] = fma_(T(0.5), fma_(om.x, qx, fma_(om.y, qy, om.z * qz)), kq * qw);
+  d[7] = fma_(T(-0.5), fma_(om.x, qw, fma_(om.y, qz, -(om.z * qy))), kq * qx);
+  d[8] = fma_(T(-0.5), fma_(om.y, qw, fma_(om.z, qx, -(om.x * qz))), kq * qy);
+  d[9] = fma_(T(-0.5), fma_(om.z, qw, fma_(om.x, qy, -(om.y * qx))), kq * qz);
+  d[10] = wd.x; d[11] = wd.y; d[12] = wd.z;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { d[13 + k] = y[16 + k]; d[16 + k] = thdd[k]; }
+}
+
+// One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states.
+template <typename T, int NROT, int KW>
+__device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act) {
+  const float Ff = (act[0] * P.mass_f) * P.g_f;
+  const T u0 = T(Ff), u1 = T(act[1] * P.mscale_f), u2 = T(act[2] * P.mscale_f), u3 = T(act[3] * P.mscale_f);
+  T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
+#pragma unroll
+  for (int r = 0; r < NROT; r++) {
+    if (NROT == AMENV_MAX_ROTORS && r >= P.n_rotors) break;
+    T t = fma_(P.alloc[r][0], u0, fma_(P.alloc[r][1], u1, fma_(P.alloc[r][2], u2, P.alloc[r][3] * u3)));
+    t = clamp_(t, P.tmin[r], P.tmax[r]);
+    F = F + t; Mx = fma_(P.mixm[0][r], t, Mx); My = fma_(P.mixm[1][r], t, My); Mz = fma_(P.mixm[2][r], t, Mz);
+  }
+  T cmd[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) cmd[k] = T(__builtin_fmaf(act[4 + k], A.half[k], A.mid[k]));
+  const V3<T> M{Mx, My, Mz};
+  T y[19] = {e.px, e.py, e.pz, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz, e.th[0], e.th[1], e.th[2], e.thd[0], e.thd[1], e.thd[2]};
+  const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+  int it = 0;
+  do {
+    T k1[19], k2[19], k3[19], k4[19], s[19];
+    arm_rhs<T>(P, A, y, F, M, cmd, k1);
+#pragma unroll
+    for (int i = 0; i < 19; i++) s[i] = fma_(hh, k1[i], y[i]);
+    arm_rhs<T>(P, A, s, F, M, cmd, k2);
+#pragma unroll
+    for (int i = 0; i < 19; i++) s[i] = fma_(hh, k2[i], y[i]);
+    arm_rhs<T>(P, A, s, F, M, cmd, k3);
+#pragma unroll
+    for (int i = 0; i < 19; i++) s[i] = fma_(h, k3[i], y[i]);
+    arm_rhs<T>(P, A, s, F, M, cmd, k4);
+#pragma unroll
+    for (int i = 0; i < 19; i++) y[i] = fma_(h6, fma_(T(2), k2[i] + k3[i], k1[i] + k4[i]), y[i]);
+  } while (++it < P.substeps);
+  const T rn = rsqrt_(fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9]))));
+  e.px = y[0]; e.py = y[1]; e.pz = y[2]; e.vx = y[3]; e.vy = y[4]; e.vz = y[5];
+  e.qw = y[6] * rn; e.qx = y[7] * rn; e.qy = y[8] * rn; e.qz = y[9] * rn;
+  e.wx = y[10]; e.wy = y[11]; e.wz = y[12];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { e.th[k] = y[13 + k]; e.thd[k] = y[16 + k]; }
+}
+
+}  // namespace amenv_dev

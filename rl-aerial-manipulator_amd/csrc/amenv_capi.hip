@@ -200,6 +200,24 @@ HotParams<T, NR> make_hot(const amenv& e) {
   return P;
 }
 
+template <typename T>
+ArmParams<T> make_arm(const amenv& e) {
+  const amenv_vehicle& v = e.cfg.vehicle;
+  ArmParams<T> A;
+  std::memset(&A, 0, sizeof(A));
+  for (int k = 0; k < 3; k++) {
+    for (int c = 0; c < 3; c++) { A.jo[k][c] = T(v.joint_origin[3 * k + c]); A.ja[k][c] = T(v.joint_axis[3 * k + c]); A.lc[k][c] = T(v.link_com[3 * k + c]); }
+    A.lm[k] = T(v.link_mass[k]);
+    const double* I = &v.link_inertia[9 * k];
+    A.li[k][0] = T(I[0]); A.li[k][1] = T(I[1]); A.li[k][2] = T(I[2]); A.li[k][3] = T(I[4]); A.li[k][4] = T(I[5]); A.li[k][5] = T(I[8]);
+    const float lo = float(v.joint_limit[2 * k]), hi = float(v.joint_limit[2 * k + 1]);
+    A.half[k] = 0.5f * (hi - lo); A.mid[k] = 0.5f * (hi + lo);
+  }
+  A.kp = T(v.joint_kp); A.kd = T(v.joint_kd); A.amax = T(v.joint_acc_max);
+  A.mtot = T(v.mass); A.inv_mtot = T(1.0 / v.mass);
+  return A;
+}
+
 ColdParams make_cold(const amenv& e) {
   const amenv_config& c = e.cfg;
   ColdParams C;
@@ -213,7 +231,7 @@ bool is_v1(const amenv_config* c) { return c->task.variant == AMENV_TASK_V1_SCAL
 int obs_dim_of(const amenv_config* c) { return is_v1(c) ? 17 : 20 + 2 * c->vehicle.n_joints; }
 int act_dim_of(const amenv_config* c) { return kActDim + c->vehicle.n_joints; }
 
-int n_float_fields(const amenv_config* c) { return AMENV_F_WP0 + 3 * c->task.num_waypoints + 3 * c->vehicle.n_joints; }
+int n_float_fields(const amenv_config* c) { return AMENV_F_WP0 + 3 * c->task.num_waypoints + 2 * c->vehicle.n_joints; }
 
 const char* validate(const amenv_config* c) {
   if (!c) return "config is NULL";
@@ -222,7 +240,9 @@ const char* validate(const amenv_config* c) {
   if (c->num_envs <= 0) return "num_envs must be > 0";
   if (c->dtype != AMENV_F32 && c->dtype != AMENV_F64) return "dtype must be AMENV_F32 or AMENV_F64";
   if (c->vehicle.n_rotors < 1 || c->vehicle.n_rotors > AMENV_MAX_ROTORS) return "n_rotors out of range";
-  if (c->vehicle.n_joints != 0) return "n_joints != 0 (arm) is not built in this version";
+  if (c->vehicle.n_joints != 0 && c->vehicle.n_joints != 3) return "n_joints must be 0 or 3";
+  if (c->vehicle.n_joints == 3 && (c->vehicle.n_rotors != 6 || c->task.num_waypoints != 1 || is_v1(c)))
+    return "the arm vehicle is built for the 6-rotor airframe, the v2 task and 1 waypoint (BASELINE config 3)";
   if (c->task.variant != AMENV_TASK_V2_SCALED20 && !is_v1(c)) return "unknown task variant";
   if (is_v1(c) && c->task.num_waypoints > 2) return "v1 tasks draw 1..2 waypoints per episode: num_waypoints (storage bound) must be 1 or 2";
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
@@ -239,23 +259,25 @@ const char* validate(const amenv_config* c) {
   return nullptr;
 }
 
-template <typename T, int NROT, int KW, int VAR>
+template <typename T, int NROT, int KW, int VAR, int NJ = 0>
 hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed) {
+  ArmArg<T, NJ> AA;
+  if constexpr (NJ > 0) AA.p = make_arm<T>(e); else AA.unused = 0;
   const HotParams<T, NROT> P = make_hot<T, NROT>(e);
   const ColdParams C = make_cold(e);
   const int bs = e.block, n_pad = e.n_tiles * 64;
   const dim3 grid((n_pad + bs - 1) / bs), block(bs);
-  const size_t lds = size_t(bs) * ObsDim<VAR>::value * sizeof(float);
+  const size_t lds = size_t(bs) * ObsDim<VAR, NJ>::value * sizeof(float);
   const StepTail tl{io.terminal_obs, io.ep_return, io.ep_len, io.stats};
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
   if (T_steps > 0) {
-    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C);
+    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C, AA);
   } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
-    hipExtLaunchKernelGGL((step_kernel<T, NROT, KW, VAR>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward, io.done,
-                          io.info, tl, P, C);
+    hipExtLaunchKernelGGL((step_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward, io.done,
+                          io.info, tl, P, C, AA);
   } else {
-    hipLaunchKernelGGL((step_kernel<T, NROT, KW, VAR>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C);
+    hipLaunchKernelGGL((step_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C, AA);
   }
   return hipGetLastError();
 }
@@ -270,6 +292,7 @@ hipError_t dispatch_k(const amenv& e, const StepIO& io, int T_steps, hipStream_t
 template <typename T>
 hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed = false) {
   const int nr = e.cfg.vehicle.n_rotors;
+  if (e.cfg.vehicle.n_joints == 3) return launch_step<T, 6, 1, VAR_V2, 3>(e, io, T_steps, s, timed);   // BASELINE config 3
   if (nr == 4) return dispatch_k<T, 4>(e, io, T_steps, s, timed);
   if (nr == 6) return dispatch_k<T, 6>(e, io, T_steps, s, timed);
   return dispatch_k<T, AMENV_MAX_ROTORS>(e, io, T_steps, s, timed);
@@ -278,7 +301,7 @@ hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStrea
 template <typename T>
 hipError_t launch_reset(const amenv& e, const uint8_t* mask, float* obs, int pad_only, hipStream_t s) {
   const int bs = 256, n_pad = e.n_tiles * 64;
-  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, e.cfg.task.num_waypoints, e.cfg.task.variant, e.tile_bytes,
+  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, e.cfg.task.num_waypoints, e.cfg.task.variant, e.cfg.vehicle.n_joints, e.tile_bytes,
                      make_cold(e), e.blob, mask, obs, pad_only);
   return hipGetLastError();
 }
@@ -347,9 +370,10 @@ int64_t amenv_bytes_per_env_step(const amenv_config* cfg) {
   if (!cfg) return 0;
   const int64_t ts = cfg->dtype == AMENV_F64 ? 8 : 4;
   const int64_t K = cfg->task.num_waypoints;
-  const int64_t rd = ts * (13 /*state*/ + 1 /*final_yaw*/ + 1 /*last_distance*/ + 1 /*ep_return*/ + 3 * K /*waypoints*/) +
-                     4 * 3 /*step,counter,flags*/ + 4 * kActDim /*action*/;
-  const int64_t wr = ts * (13 + 1 + 1) + 4 * 3 + 4 * obs_dim_of(cfg) /*obs*/ + ts /*reward*/ + 1 /*done*/ + 4 /*info*/;
+  const int64_t nj = cfg->vehicle.n_joints;
+  const int64_t rd = ts * (13 /*state*/ + 1 /*final_yaw*/ + 1 /*last_distance*/ + 1 /*ep_return*/ + 3 * K /*waypoints*/ + 2 * nj /*joints*/) +
+                     4 * 3 /*step,counter,flags*/ + 4 * act_dim_of(cfg) /*action*/;
+  const int64_t wr = ts * (13 + 1 + 1 + 2 * nj) + 4 * 3 + 4 * obs_dim_of(cfg) /*obs*/ + ts /*reward*/ + 1 /*done*/ + 4 /*info*/;
   return rd + wr;
 }
 
@@ -395,7 +419,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   char buf[160];
   std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
-                is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2", e->block);
+                is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), cfg->vehicle.n_joints ? "v2+arm3" : (is_v1(cfg) ? "v1" : "v2"), e->block);
   e->obs_dim = obs_dim_of(cfg);
   e->kname = buf;
   *out = e;
@@ -438,9 +462,9 @@ int amenv_observe(amenv* e, float* obs_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int n = e->cfg.num_envs, bs = 256, K = e->cfg.task.num_waypoints;
   if (e->cfg.dtype == AMENV_F64) {
-    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->tile_bytes, (const void*)e->blob, obs_out);
+    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->cfg.vehicle.n_joints, e->tile_bytes, (const void*)e->blob, obs_out);
   } else {
-    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->tile_bytes, (const void*)e->blob, obs_out);
+    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->cfg.vehicle.n_joints, e->tile_bytes, (const void*)e->blob, obs_out);
   }
   AMENV_HIP(e, hipGetLastError());
   return AMENV_OK;

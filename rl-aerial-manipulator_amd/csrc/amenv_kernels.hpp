@@ -15,6 +15,7 @@
 // -> (masked) auto-reset -> observation, a single launch per control step.
 #pragma once
 #include "amenv_model.hpp"
+#include "amenv_arm.hpp"
 
 namespace amenv_dev {
 
@@ -45,7 +46,7 @@ __device__ __forceinline__ int32_t* iptr(char* tile, int lane, int field) { retu
 
 static_assert(AMENV_F_WP0 == 16 && AMENV_F_FINAL_YAW == 13 && AMENV_F_LAST_DISTANCE == 14 && AMENV_F_EP_RETURN == 15, "groups 0..3 = 16 hot fields");
 
-template <typename T, int KW>
+template <typename T, int KW, int NJ = 0>
 __device__ __forceinline__ void load_env(int K, const char* tile_c, int lane, Env<T, KW>& e) {
   char* tile = const_cast<char*>(tile_c);
   const Vec4<T> g0 = *gptr<T>(tile, lane, 0), g1 = *gptr<T>(tile, lane, 1), g2 = *gptr<T>(tile, lane, 2), g3 = *gptr<T>(tile, lane, 3);
@@ -55,15 +56,22 @@ __device__ __forceinline__ void load_env(int K, const char* tile_c, int lane, En
   e.qy = g2.a; e.qz = g2.b; e.wx = g2.c; e.wy = g2.d;
   e.wz = g3.a; e.final_yaw = g3.b; e.last_distance = g3.c; e.ep_return = g3.d;
   // waypoint k = fields 16+3k .. 18+3k: contiguous floats starting in group 4
-  T w[((3 * KW + 3) / 4) * 4];
+  // (with an arm the 2*NJ joint fields follow the waypoints; NJ > 0 is only instantiated with KW = K)
+  constexpr int NG = (3 * KW + 2 * NJ + 3) / 4;
+  T w[NG * 4];
 #pragma unroll
-  for (int g = 0; g < (3 * KW + 3) / 4; g++) {
+  for (int g = 0; g < NG; g++) {
     Vec4<T> v{T(0), T(0), T(0), T(0)};
-    if (3 * K > 4 * g) v = *gptr<T>(tile, lane, 4 + g);
+    if (NJ > 0 || 3 * K > 4 * g) v = *gptr<T>(tile, lane, 4 + g);
     w[4 * g] = v.a; w[4 * g + 1] = v.b; w[4 * g + 2] = v.c; w[4 * g + 3] = v.d;
   }
 #pragma unroll
   for (int k = 0; k < KW; k++) { e.wp[k][0] = w[3 * k]; e.wp[k][1] = w[3 * k + 1]; e.wp[k][2] = w[3 * k + 2]; }
+#pragma unroll
+  for (int k = 0; k < AMENV_MAX_JOINTS; k++) {
+    e.th[k] = k < NJ ? w[3 * KW + k] : T(0);
+    e.thd[k] = k < NJ ? w[3 * KW + NJ + k] : T(0);
+  }
   e.step = iv.x; e.counter = iv.y; e.flags = iv.z; e.episode = iv.w;
 }
 
@@ -78,16 +86,20 @@ __device__ __forceinline__ void store_env_step(char* tile, int lane, const Env<T
 }
 
 // per-episode constants (waypoints), written only by lanes that were reset
-template <typename T, int KW>
+// (with an arm the joint fields share these groups and change every step: then this runs every step)
+template <typename T, int KW, int NJ = 0>
 __device__ __forceinline__ void store_env_episode(int K, char* tile, int lane, const Env<T, KW>& e) {
-  T w[((3 * KW + 3) / 4) * 4];
+  constexpr int NG = (3 * KW + 2 * NJ + 3) / 4;
+  T w[NG * 4];
 #pragma unroll
-  for (int j = 0; j < ((3 * KW + 3) / 4) * 4; j++) w[j] = T(0);
+  for (int j = 0; j < NG * 4; j++) w[j] = T(0);
 #pragma unroll
   for (int k = 0; k < KW; k++) { w[3 * k] = e.wp[k][0]; w[3 * k + 1] = e.wp[k][1]; w[3 * k + 2] = e.wp[k][2]; }
 #pragma unroll
-  for (int g = 0; g < (3 * KW + 3) / 4; g++)
-    if (3 * K > 4 * g) *gptr<T>(tile, lane, 4 + g) = Vec4<T>{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
+  for (int k = 0; k < NJ; k++) { w[3 * KW + k] = e.th[k]; w[3 * KW + NJ + k] = e.thd[k]; }
+#pragma unroll
+  for (int g = 0; g < NG; g++)
+    if (NJ > 0 || 3 * K > 4 * g) *gptr<T>(tile, lane, 4 + g) = Vec4<T>{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
 }
 
 // Stage this lane's observation row in LDS.  OD = 20 (80-B rows): five ds_write_b128, the 8 lanes of a group land on banks
@@ -186,17 +198,30 @@ struct StepIO {
 
 // Everything one lane does for one control step, state in registers.  Returns info bits;
 // `o` holds the observation to publish (post-reset when the env was auto-reset).
-template <typename T, int NROT, int KW, int VAR>
-__device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const ColdParams& C, Env<T, KW>& e, const float4 a, int i,
+template <typename T, int NJ> struct ArmArg { ArmParams<T> p; };
+template <typename T> struct ArmArg<T, 0> { int unused; };
+
+template <typename T, int KW>
+__device__ __forceinline__ void observe_joints(const Env<T, KW>& e, float* o) {   // arm extension of the v2 observation
+#pragma unroll
+  for (int k = 0; k < AMENV_MAX_JOINTS; k++) {
+    o[20 + k] = float(e.th[k] * T(0.31830988618379067154));
+    o[20 + AMENV_MAX_JOINTS + k] = float(e.thd[k] * T(0.2));
+  }
+}
+
+template <typename T, int NROT, int KW, int VAR, int NJ>
+__device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const ColdParams& C, const ArmArg<T, NJ>& AA, Env<T, KW>& e, const float* act, int i,
                                               bool active, T& reward, float* o, const StepIO& io, char* tile, int lane,
                                               bool have_episode, bool& was_reset, int& ep_len_out, float& ep_ret_out) {
-  constexpr int OD = ObsDim<VAR>::value;
+  constexpr int OD = ObsDim<VAR, NJ>::value;
   const int K = KW == 1 ? 1 : P.K;
-  dynamics<T, NROT, KW>(P, e, a.x, a.y, a.z, a.w);
+  if constexpr (NJ > 0) { dynamics_arm<T, NROT, KW>(P, AA.p, e, act); } else { dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]); }
   uint32_t bits;
   if constexpr (VAR == VAR_V1) { bits = task_step_v1<T, KW>(P, e, reward); } else { bits = task_step<T, KW>(P, e, reward); }
   e.ep_return += reward;
   if constexpr (VAR == VAR_V1) { observe_v1<T, KW>(P.raw_obs != 0, e, o); } else { observe<T, KW>(K, e, o); }
+  if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
   was_reset = false;
   ep_len_out = 0; ep_ret_out = 0.0f;
   const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
@@ -223,6 +248,7 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
       if (resets) {
         if constexpr (VAR == VAR_V1) { reset_from_words_v1<T, KW>(K, e, r); observe_v1<T, KW>(P.raw_obs != 0, e, o); }
         else { reset_from_words<T, KW>(C, K, e, r); observe<T, KW>(K, e, o); }
+        if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
         bits |= AMENV_INFO_WAS_RESET;
         was_reset = true;
       }
@@ -256,10 +282,12 @@ constexpr int kStampSlots = 8, kStampWaves = 64, kStampBase = 16;
 struct StepTail { float* terminal_obs; float* ep_return; int32_t* ep_len; unsigned long long* stats; };
 struct Head { void* blob; uint32_t tile_bytes; int32_t n; };
 
-template <typename T, int NROT, int KW, int VAR>
+template <typename T, int NROT, int KW, int VAR, int NJ>
 __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
                                                    float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
-                                                   uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C) {
+                                                   uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C,
+                                                   const ArmArg<T, NJ> AA) {
+  constexpr int OD = ObsDim<VAR, NJ>::value, AD = kActDim + NJ;
 #ifdef AMENV_STAMPS
   unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -274,18 +302,26 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
   char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
   const int K = KW == 1 ? 1 : P.K;
   Env<T, KW> e;
-  load_env<T, KW>(K, tile, lane, e);
-  const float4 a = io.actions[min(i, hd.n - 1)];  // padding lanes re-read the last env's action: no exec branch in the prologue
+  load_env<T, KW, NJ>(K, tile, lane, e);
+  float act[AD];
+  if constexpr (NJ == 0) {
+    const float4 a = io.actions[min(i, hd.n - 1)];  // padding lanes re-read the last env's action: no exec branch in the prologue
+    act[0] = a.x; act[1] = a.y; act[2] = a.z; act[3] = a.w;
+  } else {
+    const float* ap = reinterpret_cast<const float*>(io.actions) + size_t(min(i, hd.n - 1)) * AD;   // 28-B rows: dword loads
+#pragma unroll
+    for (int j = 0; j < AD; j++) act[j] = ap[j];
+  }
   AMENV_STAMP(1);          // loads issued
   AMENV_STAMP_DRAIN();
   AMENV_STAMP(2);          // loads landed
   T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
-  uint32_t bits = step_lane<T, NROT, KW, VAR>(P, C, e, a, i, active, reward, o, io, tile, lane, false, was_reset, ep_len, ep_ret);
+  uint32_t bits = step_lane<T, NROT, KW, VAR, NJ>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len, ep_ret);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   AMENV_STAMP(3);          // dynamics + task + obs computed
   accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
   store_env_step<T, KW>(tile, lane, e);
-  if (was_reset) store_env_episode<T, KW>(K, tile, lane, e);
+  if (NJ > 0 || was_reset) store_env_episode<T, KW, NJ>(K, tile, lane, e);
   if (active) {
     reinterpret_cast<T*>(io.reward)[i] = reward;
     io.done[i] = is_done ? 1 : 0;
@@ -294,17 +330,17 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
   AMENV_STAMP(4);          // state/outputs stores issued
 #ifdef AMENV_DIAG_DIRECT_OBS
   if (active) {
-    float4* d = reinterpret_cast<float4*>(io.obs + size_t(i) * ObsDim<VAR>::value);
+    float4* d = reinterpret_cast<float4*>(io.obs + size_t(i) * OD);
 #pragma unroll
     for (int j = 0; j < 5; j++) d[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
   }
   (void)lds;
 #else
-  stage_obs<ObsDim<VAR>::value>(lds + threadIdx.x * ObsDim<VAR>::value, o);
+  stage_obs<OD>(lds + threadIdx.x * OD, o);
   __syncthreads();
   const int row0 = blockIdx.x * BS;
   const int rows = min(BS, hd.n - row0);
-  flush_obs<ObsDim<VAR>::value>(lds, io.obs + size_t(row0) * ObsDim<VAR>::value, rows);
+  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, rows);
 #endif
   AMENV_STAMP(5);          // obs flushed
   AMENV_STAMP(6);
@@ -319,11 +355,12 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
 
 // n_steps control steps per launch with open-loop actions [T][N][4]; per-step outputs [T][N]...
 // State stays in registers across steps: HBM traffic per env-step drops to action + outputs.
-template <typename T, int NROT, int KW, int VAR>
+template <typename T, int NROT, int KW, int VAR, int NJ>
 __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
                                                       float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
                                                       uint32_t* __restrict__ info, int n_steps, const StepTail tl, const HotParams<T, NROT> P,
-                                                      const ColdParams C) {
+                                                      const ColdParams C, const ArmArg<T, NJ> AA) {
+  constexpr int OD = ObsDim<VAR, NJ>::value, AD = kActDim + NJ;
   const Head hd{blob, tile_bytes, n_envs};
   const StepIO io{actions, obs, reward_out, done, info, nullptr, nullptr, nullptr, tl.stats};
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -337,13 +374,21 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
   char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
   const int K = KW == 1 ? 1 : P.K;
   Env<T, KW> e;
-  load_env<T, KW>(K, tile, lane, e);
+  load_env<T, KW, NJ>(K, tile, lane, e);
   bool any_reset = false;
   StepIO io_t = io; io_t.terminal_obs = nullptr; io_t.ep_return = nullptr; io_t.ep_len = nullptr;
   for (int t = 0; t < n_steps; t++) {
-    const float4 a = io.actions[size_t(t) * n + min(i, hd.n - 1)];
+    float act[AD];
+    {
+      const float* ap = reinterpret_cast<const float*>(io.actions) + (size_t(t) * n + min(i, hd.n - 1)) * AD;
+      if constexpr (NJ == 0) { const float4 a = *reinterpret_cast<const float4*>(ap); act[0] = a.x; act[1] = a.y; act[2] = a.z; act[3] = a.w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < AD; j++) act[j] = ap[j];
+      }
+    }
     T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
-    uint32_t bits = step_lane<T, NROT, KW, VAR>(P, C, e, a, i, active, reward, o, io_t, tile, lane, any_reset, was_reset, ep_len, ep_ret);
+    uint32_t bits = step_lane<T, NROT, KW, VAR, NJ>(P, C, AA, e, act, i, active, reward, o, io_t, tile, lane, any_reset, was_reset, ep_len, ep_ret);
     any_reset |= was_reset;
     const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
     accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
@@ -353,23 +398,23 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
       if (io.info) io.info[size_t(t) * n + i] = bits;
     }
     if (io.obs) {
-      stage_obs<ObsDim<VAR>::value>(lds + threadIdx.x * ObsDim<VAR>::value, o);
+      stage_obs<OD>(lds + threadIdx.x * OD, o);
       __syncthreads();
-      flush_obs<ObsDim<VAR>::value>(lds, io.obs + (size_t(t) * n + row0) * ObsDim<VAR>::value, rows);
+      flush_obs<OD>(lds, io.obs + (size_t(t) * n + row0) * OD, rows);
       __syncthreads();
     }
   }
   store_env_step<T, KW>(tile, lane, e);
-  if (any_reset) store_env_episode<T, KW>(K, tile, lane, e);
+  if (NJ > 0 || any_reset) store_env_episode<T, KW, NJ>(K, tile, lane, e);
 }
 
 // WaypointQuadEnv.reset for masked envs (mask null = all) + observation of every env.
 // Launched over whole tiles: padding lanes (i >= n) are always reset so that they hold a valid state.
 template <typename T>
-__global__ void reset_kernel(int n, int K, int variant, uint32_t tile_bytes, const ColdParams C, void* __restrict__ blob,
+__global__ void reset_kernel(int n, int K, int variant, int nj, uint32_t tile_bytes, const ColdParams C, void* __restrict__ blob,
                              const uint8_t* __restrict__ mask, float* __restrict__ obs, int pad_only) {
   const bool v1 = variant != AMENV_TASK_V2_SCALED20;
-  const int od = v1 ? 17 : 20;
+  const int od = v1 ? 17 : 20 + 2 * nj;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool active = i < n;
@@ -381,27 +426,37 @@ __global__ void reset_kernel(int n, int K, int variant, uint32_t tile_bytes, con
     reset_env<T, AMENV_MAX_WAYPOINTS>(C, K, v1, e, C.gid0 + i);
     store_env_step<T, AMENV_MAX_WAYPOINTS>(tile, lane, e);
     store_env_episode<T, AMENV_MAX_WAYPOINTS>(K, tile, lane, e);
+    for (int j = 0; j < 2 * nj; j++) *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j) = T(0);   // arm at home, at rest
   }
   if (obs && active) {
     float o[kObsDimMax];
     if (v1) observe_v1<T, AMENV_MAX_WAYPOINTS>(variant == AMENV_TASK_V1_RAW17, e, o);
     else observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
+    for (int j = 0; j < nj; j++) {   // joints are not in the generic Env load: read them from the tile (zero after a reset)
+      o[20 + j] = float(*fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j) * T(0.31830988618379067154));
+      o[20 + nj + j] = float(*fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + nj + j) * T(0.2));
+    }
     for (int j = 0; j < od; j++) obs[size_t(i) * od + j] = o[j];
   }
 }
 
 // _get_observation of the current state for every env (no stepping).
 template <typename T>
-__global__ void observe_kernel(int n, int K, int variant, uint32_t tile_bytes, const void* __restrict__ blob, float* __restrict__ obs) {
+__global__ void observe_kernel(int n, int K, int variant, int nj, uint32_t tile_bytes, const void* __restrict__ blob, float* __restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const bool v1 = variant != AMENV_TASK_V2_SCALED20;
-  const int od = v1 ? 17 : 20;
+  const int od = v1 ? 17 : 20 + 2 * nj;
   Env<T, AMENV_MAX_WAYPOINTS> e;
   load_env<T, AMENV_MAX_WAYPOINTS>(K, tile_base(blob, tile_bytes, i), threadIdx.x & 63, e);
   float o[kObsDimMax];
   if (v1) observe_v1<T, AMENV_MAX_WAYPOINTS>(variant == AMENV_TASK_V1_RAW17, e, o);
   else observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
+  char* tile = const_cast<char*>(tile_base(blob, tile_bytes, i));
+  for (int j = 0; j < nj; j++) {
+    o[20 + j] = float(*fptr<T>(tile, threadIdx.x & 63, AMENV_F_WP0 + 3 * K + j) * T(0.31830988618379067154));
+    o[20 + nj + j] = float(*fptr<T>(tile, threadIdx.x & 63, AMENV_F_WP0 + 3 * K + nj + j) * T(0.2));
+  }
   for (int j = 0; j < od; j++) obs[size_t(i) * od + j] = o[j];
 }
 

@@ -26,8 +26,8 @@ namespace amenv_dev {
 
 constexpr int kActDim = 4;
 enum TaskVar { VAR_V2 = 0, VAR_V1 = 1 };                 // v2/rl_env_scaledObs.py | v1/rl_env_scaledObs.py + v1/rl_env.py
-template <int VAR> struct ObsDim { static constexpr int value = VAR == VAR_V1 ? 17 : 20; };
-constexpr int kObsDimMax = 20;
+template <int VAR, int NJ = 0> struct ObsDim { static constexpr int value = VAR == VAR_V1 ? 17 : 20 + 2 * NJ; };   // + joint angle, rate per joint
+constexpr int kObsDimMax = 26;
 
 // ---- kernel-argument constants (uniform: they live in SGPRs) ----------------------------------
 // Hot parameters are kept COMPACT (rotor-count-sized mixer, symmetric inertia) so that one batch of
@@ -107,6 +107,7 @@ struct Env {
   T px, py, pz, vx, vy, vz, qw, qx, qy, qz, wx, wy, wz;
   T wp[KW][3];
   T final_yaw, last_distance, ep_return;
+  T th[AMENV_MAX_JOINTS], thd[AMENV_MAX_JOINTS];   // arm joint angles / rates (unused, and eliminated, without an arm)
   int32_t step, counter, flags, episode;
 };
 
@@ -408,6 +409,8 @@ __device__ __forceinline__ void reset_from_words_v1(int Kmax, Env<T, KW>& e, con
     e.wp[k][2] = on ? T(fmaf(2.0f, u01(r[b + 2]), 1.0f)) : T(0);
   }
   e.final_yaw = T(0); e.last_distance = T(-1); e.ep_return = T(0);
+#pragma unroll
+  for (int k = 0; k < AMENV_MAX_JOINTS; k++) { e.th[k] = T(0); e.thd[k] = T(0); }
   e.step = 0; e.counter = 0; e.flags = K << 4;
   e.episode += 1;
 }
@@ -500,6 +503,8 @@ __device__ __forceinline__ void reset_from_words(const ColdParams& P, int K, Env
   e.qw = T(1); e.qx = e.qy = e.qz = T(0);                               // quadcopter.py:28-38, attitude (0,0,0)
   e.wx = e.wy = e.wz = T(0);
   e.final_yaw = T(fyaw);
+#pragma unroll
+  for (int k = 0; k < AMENV_MAX_JOINTS; k++) { e.th[k] = T(0); e.thd[k] = T(0); }     // arm at home
   e.last_distance = T(-1);                                              // :76 None
   e.ep_return = T(0);
   e.step = 0; e.counter = 0; e.flags = 0;                               // :55-59,74-77

@@ -51,12 +51,15 @@ class Box:
         return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
 
 
-def make_spaces(obs_dim=20):
+def make_spaces(obs_dim=20, act_dim=4):
     """observation_space / action_space of WaypointQuadEnv (v2/rl_env_scaledObs.py:14-24; 17-D for the v1 envs,
     v1/rl_env_scaledObs.py:13-23)."""
     B = _spaces.Box if _spaces is not None else Box
     obs = B(low=-np.inf, high=np.inf, shape=(int(obs_dim),), dtype=np.float32)
-    act = B(low=np.array([0, -1, -1, -1], dtype=np.float32), high=np.array([2.0, 1, 1, 1], dtype=np.float32), dtype=np.float32)
+    # thrust in [0, 2], moments (and, with the arm, joint position commands) in [-1, 1]
+    lo = np.array([0.0] + [-1.0] * (int(act_dim) - 1), dtype=np.float32)
+    hi = np.array([2.0] + [1.0] * (int(act_dim) - 1), dtype=np.float32)
+    act = B(low=lo, high=hi, dtype=np.float32)
     return obs, act
 
 
@@ -89,7 +92,7 @@ class GpuVecEnv(_SB3VecEnv):
             from .gpu_env import GpuWaypointEnv
             backend = GpuWaypointEnv(int(n), device=device, auto_reset=True, **env_kwargs)
         self.backend = backend
-        obs_space, act_space = make_spaces(getattr(backend, "obs_dim", 20))
+        obs_space, act_space = make_spaces(getattr(backend, "obs_dim", 20), getattr(backend, "act_dim", 4))
         if _SB3VecEnv is not object:
             super().__init__(backend.num_envs, obs_space, act_space)
         else:
@@ -105,7 +108,7 @@ class GpuVecEnv(_SB3VecEnv):
         return self._to_numpy(self.backend.reset())
 
     def step_async(self, actions):
-        self._actions = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, 4)
+        self._actions = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.num_envs, -1)
 
     def step_wait(self):
         import torch

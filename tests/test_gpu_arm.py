@@ -1,0 +1,147 @@
+"""BASELINE config 3 on the GPU: hexacopter + 3-joint arm.  No reference dynamics exist for this vehicle (parity
+unpinned): the HIP kernel is checked against the fp64 oracle of the same specified model (which tests/test_arm_cpu.py pins
+by physical invariants), and directly against momentum conservation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.test_arm_cpu import arm_cfg, momenta
+from tests.test_gpu_parity import gpu_state, rel_err, REL32, OBS_ULP
+
+pytestmark = pytest.mark.gpu
+
+
+def orc_arm(n, seed=0, flags=O.FLAG_AUTO_RESET, **over):
+    cfg = arm_cfg(**over)
+    cfg.num_envs = n; cfg.seed = seed; cfg.flags = flags
+    return O.OracleEnv(cfg)
+
+
+def both_step(env, orc, a):
+    import torch
+    f, i = gpu_state(env)
+    orc.fstate[:] = f; orc.istate[:] = i
+    obs, rew, done, info = env.step(torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda())
+    torch.cuda.synchronize()
+    g = dict(obs=obs.cpu().numpy().copy(), reward=rew.cpu().numpy().astype(np.float64), done=done.cpu().numpy().copy(),
+             info=info.cpu().numpy().view(np.uint32).copy())
+    return g, orc.step(a)
+
+
+def rand_actions(rng, n, scale=0.05):
+    a = rng.uniform([0.6, -1, -1, -1, -1, -1, -1], [1.4, 1, 1, 1, 1, 1, 1], (n, 7)).astype(np.float32)
+    a[:, 1:4] *= scale
+    return a
+
+
+def test_arm_dims_and_reset():
+    import rl_aerial_manipulator_amd as amd
+    n = 1000
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=5)
+    assert (env.obs_dim, env.act_dim, env.n_float_fields) == (26, 7, 25) and "arm3" in env.kernel_name
+    orc = orc_arm(n, seed=5)
+    obs = env.reset().cpu().numpy(); oobs = orc.reset()
+    f, i = gpu_state(env)
+    assert np.array_equal(f, orc.fstate) and np.array_equal(i, orc.istate) and (f[19:25] == 0).all()
+    np.testing.assert_allclose(obs, oobs, rtol=OBS_ULP, atol=1e-9)
+    assert env.bytes_per_env_step == 4 * (13 + 3 + 3 + 6) + 12 + 28 + 4 * (15 + 6) + 12 + 104 + 4 + 1 + 4
+    env.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", REL32), ("f64", 1e-10)])
+def test_arm_closed_loop_vs_oracle(dtype, tol):
+    """Teacher-forced per step (the oracle is re-seated on the GPU state each step), joints slewing, with resets."""
+    import rl_aerial_manipulator_amd as amd
+    n = 2048
+    rng = np.random.RandomState(3)
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=9, dtype=dtype, max_episode_steps=120)
+    orc = orc_arm(n, seed=9)
+    orc.cfg.task.max_episode_steps = 120
+    env.reset()
+    # start from disturbed attitudes / rates / joint states so every coupling term is exercised
+    f, i = gpu_state(env)
+    q = rng.normal(size=(4, n)) * 0.2; q[0] += 1; q /= np.linalg.norm(q, axis=0)
+    f[6:10] = q; f[10:13] = rng.normal(0, 1.0, (3, n)); f[3:6] = rng.normal(0, 0.5, (3, n))
+    f[19:22] = rng.uniform(-1, 1, (3, n)); f[22:25] = rng.normal(0, 1.0, (3, n))
+    env.set_state(f if dtype == "f64" else f.astype(np.float32), i)
+    worst = 0.0; flips = 0; dones = 0; worst_obs = 0.0
+    for t in range(150):
+        a = rand_actions(rng, n)
+        a[::9, 0] = 0.0
+        g, o = both_step(env, orc, a)
+        f2, i2 = gpu_state(env)
+        bad = np.nonzero((g["info"] & 127) != (o["info"] & 127))[0]
+        flips += len(bad)
+        ok = np.ones(n, bool); ok[bad] = False
+        nd = ok & (o["done"] == 0)
+        worst = max(worst, rel_err(f2[:, nd], orc.fstate[:, nd]).max())
+        worst_obs = max(worst_obs, rel_err(g["obs"][ok], o["obs"][ok]).max())
+        dn = ok & (o["done"] != 0)
+        dones += int(dn.sum())
+        assert np.array_equal(f2[:, dn], orc.fstate[:, dn]) and np.array_equal(i2[:, ok], orc.istate[:, ok])
+    assert worst < tol, worst
+    assert worst_obs < max(tol, 1.3e-7) and flips <= 4 and dones > 100, (worst_obs, flips, dones)
+    env.close()
+
+
+def test_arm_momentum_conservation_on_gpu():
+    """g = 0, zero rotor wrench, joints slewing: total linear / angular momentum of the GPU trajectory stay constant
+    (fp64 build: integration error only; fp32 build: rounding-limited)."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n = 64
+    for dtype, tol in (("f64", 5e-9), ("f32", 2e-4)):
+        cfg = amd._lib.default_config("hexa_arm", n)
+        cfg.vehicle.g = 0.0
+        for r in range(8):
+            cfg.vehicle.t_min[r] = 0.0
+        cfg.dtype = amd._lib.F64 if dtype == "f64" else amd._lib.F32
+        cfg.flags = 0
+        env = amd.GpuWaypointEnv(n, config=cfg)
+        env.reset()
+        rng = np.random.RandomState(0)
+        f, i = gpu_state(env)
+        q = rng.normal(size=(4, n)); q /= np.linalg.norm(q, axis=0)
+        f[6:10] = q; f[3:6] = rng.normal(0, 0.3, (3, n)); f[10:13] = rng.normal(0, 0.7, (3, n)); f[19:22] = rng.uniform(-0.5, 0.5, (3, n))
+        env.set_state(f if dtype == "f64" else f.astype(np.float32), i)
+        f, _ = gpu_state(env)
+        ocfg = arm_cfg(g=0.0)
+        s_of = lambda F, k: np.concatenate([F[0:13, k], F[19:25, k]])
+        P0 = [momenta(ocfg, s_of(f, k)) for k in range(n)]
+        a = np.zeros((n, 7), np.float32); a[:, 4:] = rng.uniform(-1, 1, (n, 3))
+        at = torch.from_numpy(a).cuda()
+        for t in range(300):
+            env.step(at)
+        f, _ = gpu_state(env)
+        worst = 0.0
+        for k in range(n):
+            P, L, _ = momenta(ocfg, s_of(f, k))
+            worst = max(worst, np.abs(P - P0[k][0]).max() / max(1e-3, np.abs(P0[k][0]).max()), np.abs(L - P0[k][1]).max() / max(1e-3, np.abs(P0[k][1]).max()))
+        assert np.abs(f[22:25]).max() < 5 and np.abs(f[19:22] - 0).max() > 0.3
+        assert worst < tol, (dtype, worst)
+        env.close()
+
+
+def test_arm_rollout_equals_steps_and_vecenv():
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n, T = 300, 40
+    rng = np.random.RandomState(2)
+    a = np.stack([rand_actions(rng, n) for _ in range(T)])
+    a[:, ::7, 0] = 0.0
+    at = torch.from_numpy(a).cuda()
+    e1 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30); e2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30)
+    e1.reset(); e2.reset()
+    ro = e1.rollout(at)
+    assert ro["obs"].shape == (T, n, 26)
+    for t in range(T):
+        obs, rew, done, info = e2.step(at[t])
+        assert torch.equal(ro["obs"][t], obs) and torch.equal(ro["reward"][t], rew) and torch.equal(ro["info_bits"][t], info)
+    assert ro["done"].sum().item() > 0
+    ve = amd.GpuVecEnv(num_envs=64, vehicle="hexa_arm")
+    assert ve.observation_space.shape == (26,) and ve.action_space.shape == (7,)
+    o, r, d, inf = ve.step(np.tile(np.array([1, 0, 0, 0, 0.2, -0.2, 0.1], np.float32), (64, 1)))
+    assert o.shape == (64, 26) and np.isfinite(o).all()
+    e1.close(); e2.close(); ve.close()
