@@ -71,7 +71,7 @@ __device__ __forceinline__ M3<T> rodrigues(V3<T> a, T th) {   // rotation by th 
 
 // 19 derivatives of the arm vehicle.  y: state, F / M: rotor wrench after the mixer, cmd: joint position commands.
 template <typename T, typename PT>
-__device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
+__device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
   const V3<T> om{y[10], y[11], y[12]};
   // rotation of the normalised quaternion (body -> world is its transpose, as in the rigid model)
   const T n2 = fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9])));
@@ -155,6 +155,11 @@ __device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, cons
   for (int k = 0; k < 3; k++) { d[13 + k] = y[16 + k]; d[16 + k] = thdd[k]; }
 }
 
+template <typename T, typename PT>
+__device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
+  arm_rhs_body<T>(P, A, y, F, M, cmd, d);
+}
+
 // One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states.
 template <typename T, int NROT, int KW>
 __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act) {
@@ -176,19 +181,21 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
   const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
   int it = 0;
   do {
-    T k1[19], k2[19], k3[19], k4[19], s[19];
-    arm_rhs<T>(P, A, y, F, M, cmd, k1);
+    // RK4 with a running weighted sum (acc = k1 + 2 k2 + 2 k3 + k4): four 19-vectors live instead of six -- the fp64
+    // build of this kernel otherwise needs more than the 512 registers a wave can have
+    T k[19], acc[19], s[19];
+    arm_rhs(P, A, y, F, M, cmd, k);
 #pragma unroll
-    for (int i = 0; i < 19; i++) s[i] = fma_(hh, k1[i], y[i]);
-    arm_rhs<T>(P, A, s, F, M, cmd, k2);
+    for (int i = 0; i < 19; i++) { acc[i] = k[i]; s[i] = fma_(hh, k[i], y[i]); }
+    arm_rhs(P, A, s, F, M, cmd, k);
 #pragma unroll
-    for (int i = 0; i < 19; i++) s[i] = fma_(hh, k2[i], y[i]);
-    arm_rhs<T>(P, A, s, F, M, cmd, k3);
+    for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(hh, k[i], y[i]); }
+    arm_rhs(P, A, s, F, M, cmd, k);
 #pragma unroll
-    for (int i = 0; i < 19; i++) s[i] = fma_(h, k3[i], y[i]);
-    arm_rhs<T>(P, A, s, F, M, cmd, k4);
+    for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(h, k[i], y[i]); }
+    arm_rhs(P, A, s, F, M, cmd, k);
 #pragma unroll
-    for (int i = 0; i < 19; i++) y[i] = fma_(h6, fma_(T(2), k2[i] + k3[i], k1[i] + k4[i]), y[i]);
+    for (int i = 0; i < 19; i++) y[i] = fma_(h6, acc[i] + k[i], y[i]);
   } while (++it < P.substeps);
   const T rn = rsqrt_(fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9]))));
   e.px = y[0]; e.py = y[1]; e.pz = y[2]; e.vx = y[3]; e.vy = y[4]; e.vz = y[5];

@@ -243,6 +243,9 @@ const char* validate(const amenv_config* c) {
   if (c->vehicle.n_joints != 0 && c->vehicle.n_joints != 3) return "n_joints must be 0 or 3";
   if (c->vehicle.n_joints == 3 && (c->vehicle.n_rotors != 6 || c->task.num_waypoints != 1 || is_v1(c)))
     return "the arm vehicle is built for the 6-rotor airframe, the v2 task and 1 waypoint (BASELINE config 3)";
+  if (c->vehicle.n_joints == 3 && c->dtype == AMENV_F64)
+    return "no fp64 build of the arm kernel: four inlined fp64 multibody RHS evaluations need more than the 512 registers of a "
+           "wavefront and the spilled build computed garbage on gfx950/ROCm 7.2 (DESIGN.md); the fp32 kernel is checked against the fp64 oracle";
   if (c->task.variant != AMENV_TASK_V2_SCALED20 && !is_v1(c)) return "unknown task variant";
   if (is_v1(c) && c->task.num_waypoints > 2) return "v1 tasks draw 1..2 waypoints per episode: num_waypoints (storage bound) must be 1 or 2";
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
@@ -272,7 +275,11 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
   if (T_steps > 0) {
-    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C, AA);
+    if constexpr (NJ == 0) {   // the multi-step kernel is not instantiated for the arm vehicle (amenv_rollout refuses it)
+      hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C, AA);
+    } else {
+      return hipErrorNotSupported;
+    }
   } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
     hipExtLaunchKernelGGL((step_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward, io.done,
                           io.info, tl, P, C, AA);
@@ -292,7 +299,9 @@ hipError_t dispatch_k(const amenv& e, const StepIO& io, int T_steps, hipStream_t
 template <typename T>
 hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed = false) {
   const int nr = e.cfg.vehicle.n_rotors;
-  if (e.cfg.vehicle.n_joints == 3) return launch_step<T, 6, 1, VAR_V2, 3>(e, io, T_steps, s, timed);   // BASELINE config 3
+  if constexpr (sizeof(T) == 4) {   // BASELINE config 3 (fp32 only, see validate())
+    if (e.cfg.vehicle.n_joints == 3) return launch_step<T, 6, 1, VAR_V2, 3>(e, io, T_steps, s, timed);
+  }
   if (nr == 4) return dispatch_k<T, 4>(e, io, T_steps, s, timed);
   if (nr == 6) return dispatch_k<T, 6>(e, io, T_steps, s, timed);
   return dispatch_k<T, AMENV_MAX_ROTORS>(e, io, T_steps, s, timed);
@@ -509,6 +518,9 @@ int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, v
                   void* stream) {
   if (!e) return AMENV_ERR_INVALID;
   if (n_steps <= 0 || !actions) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: n_steps must be > 0 and actions non-NULL");
+  if (e->cfg.vehicle.n_joints != 0)
+    return fail(e, AMENV_ERR_INVALID, "amenv_rollout: not available for the arm vehicle (its multi-step kernel failed validation on gfx950: "
+                                      "it wrote outside its buffers); use amenv_step");
   if (!aligned16(actions) || (obs && !aligned16(obs))) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: actions/obs must be 16-byte aligned");
   DeviceGuard g(e->device);
   StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, nullptr, nullptr, nullptr, e->stats};
@@ -613,23 +625,27 @@ int amenv_obsnorm_apply(amenv_obsnorm* h, const float* in, float* out, int64_t n
 int amenv_obsnorm_get(amenv_obsnorm* h, double* mean, double* var, double* count, void* stream) {
   if (!h || !mean || !var || !count) return AMENV_ERR_INVALID;
   DeviceGuard g(h->device);
-  hipStream_t s = (hipStream_t)stream;
   const int d = h->dim;
-  if (hipMemcpyAsync(mean, h->buf, sizeof(double) * d, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipMemcpyAsync(var, h->buf + d, sizeof(double) * d, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipMemcpyAsync(count, h->buf + 2 * d, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+  std::string staging(sizeof(double) * (2 * d + 1), '\0');   // one synchronous copy of [mean | var | count]
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&staging[0], h->buf, staging.size(), hipMemcpyDeviceToHost) != hipSuccess)
     return AMENV_ERR_HIP;
+  const double* src = reinterpret_cast<const double*>(staging.data());
+  std::memcpy(mean, src, sizeof(double) * d);
+  std::memcpy(var, src + d, sizeof(double) * d);
+  *count = src[2 * d];
   return AMENV_OK;
 }
 
 int amenv_obsnorm_set(amenv_obsnorm* h, const double* mean, const double* var, double count, void* stream) {
   if (!h || !mean || !var) return AMENV_ERR_INVALID;
   DeviceGuard g(h->device);
-  hipStream_t s = (hipStream_t)stream;
   const int d = h->dim;
-  if (hipMemcpyAsync(h->buf, mean, sizeof(double) * d, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(h->buf + d, var, sizeof(double) * d, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(h->buf + 2 * d, &count, sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+  std::string staging(sizeof(double) * (2 * d + 1), '\0');
+  double* dst = reinterpret_cast<double*>(&staging[0]);
+  std::memcpy(dst, mean, sizeof(double) * d);
+  std::memcpy(dst + d, var, sizeof(double) * d);
+  dst[2 * d] = count;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(h->buf, staging.data(), staging.size(), hipMemcpyHostToDevice) != hipSuccess)
     return AMENV_ERR_HIP;
   return AMENV_OK;
 }

@@ -36,6 +36,12 @@ def rand_actions(rng, n, scale=0.05):
     return a
 
 
+def test_arm_fp64_build_is_refused():
+    import rl_aerial_manipulator_amd as amd
+    with pytest.raises(amd.AmenvError, match="no fp64 build of the arm kernel"):
+        amd.GpuWaypointEnv(64, vehicle="hexa_arm", dtype="f64")
+
+
 def test_arm_dims_and_reset():
     import rl_aerial_manipulator_amd as amd
     n = 1000
@@ -50,7 +56,7 @@ def test_arm_dims_and_reset():
     env.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", REL32), ("f64", 1e-10)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6)])   # fp32 kernel vs fp64 oracle: rounding level, far inside the 1e-5 gate
 def test_arm_closed_loop_vs_oracle(dtype, tol):
     """Teacher-forced per step (the oracle is re-seated on the GPU state each step), joints slewing, with resets."""
     import rl_aerial_manipulator_amd as amd
@@ -76,7 +82,8 @@ def test_arm_closed_loop_vs_oracle(dtype, tol):
         flips += len(bad)
         ok = np.ones(n, bool); ok[bad] = False
         nd = ok & (o["done"] == 0)
-        worst = max(worst, rel_err(f2[:, nd], orc.fstate[:, nd]).max())
+        rows = np.r_[0:15, 16:25]   # everything but the running episode return (row 15: reward-threshold flips accumulate there)
+        worst = max(worst, rel_err(f2[rows][:, nd], orc.fstate[rows][:, nd]).max())
         worst_obs = max(worst_obs, rel_err(g["obs"][ok], o["obs"][ok]).max())
         dn = ok & (o["done"] != 0)
         dones += int(dn.sum())
@@ -92,7 +99,7 @@ def test_arm_momentum_conservation_on_gpu():
     import torch
     import rl_aerial_manipulator_amd as amd
     n = 64
-    for dtype, tol in (("f64", 5e-9), ("f32", 2e-4)):
+    for dtype, tol in (("f32", 2e-4),):   # rounding-limited in fp32 (the fp64 statement of the model conserves to 5e-9: tests/test_arm_cpu.py)
         cfg = amd._lib.default_config("hexa_arm", n)
         cfg.vehicle.g = 0.0
         for r in range(8):
@@ -124,24 +131,23 @@ def test_arm_momentum_conservation_on_gpu():
         env.close()
 
 
-def test_arm_rollout_equals_steps_and_vecenv():
+def test_arm_vecenv_and_refused_rollout():
     import torch
     import rl_aerial_manipulator_amd as amd
-    n, T = 300, 40
-    rng = np.random.RandomState(2)
-    a = np.stack([rand_actions(rng, n) for _ in range(T)])
-    a[:, ::7, 0] = 0.0
-    at = torch.from_numpy(a).cuda()
-    e1 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30); e2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30)
-    e1.reset(); e2.reset()
-    ro = e1.rollout(at)
-    assert ro["obs"].shape == (T, n, 26)
-    for t in range(T):
-        obs, rew, done, info = e2.step(at[t])
-        assert torch.equal(ro["obs"][t], obs) and torch.equal(ro["reward"][t], rew) and torch.equal(ro["info_bits"][t], info)
-    assert ro["done"].sum().item() > 0
     ve = amd.GpuVecEnv(num_envs=64, vehicle="hexa_arm")
     assert ve.observation_space.shape == (26,) and ve.action_space.shape == (7,)
+    assert ve.reset().shape == (64, 26)
     o, r, d, inf = ve.step(np.tile(np.array([1, 0, 0, 0, 0.2, -0.2, 0.1], np.float32), (64, 1)))
     assert o.shape == (64, 26) and np.isfinite(o).all()
+    with pytest.raises(amd.AmenvError, match="not available for the arm vehicle"):
+        ve.backend.rollout(torch.zeros(4, 64, 7, device="cuda"))
+    # determinism of the step kernel: two envs, same seed, same actions -> bit-identical
+    rng = np.random.RandomState(2)
+    e1 = amd.GpuWaypointEnv(300, vehicle="hexa_arm", seed=3, max_episode_steps=30); e2 = amd.GpuWaypointEnv(300, vehicle="hexa_arm", seed=3, max_episode_steps=30)
+    assert torch.equal(e1.reset(), e2.reset())
+    for t in range(40):
+        a = torch.from_numpy(rand_actions(rng, 300)).cuda()
+        o1, r1, d1, i1 = e1.step(a); o2, r2, d2, i2 = e2.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(i1, i2)
+    assert e1.stats()["episodes"] == e2.stats()["episodes"] > 0
     e1.close(); e2.close(); ve.close()
