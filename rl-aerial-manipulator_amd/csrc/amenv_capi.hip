@@ -310,7 +310,7 @@ hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStrea
 template <typename T>
 hipError_t launch_reset(const amenv& e, const uint8_t* mask, float* obs, int pad_only, hipStream_t s) {
   const int bs = 256, n_pad = e.n_tiles * 64;
-  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, e.cfg.task.num_waypoints, e.cfg.task.variant, e.cfg.vehicle.n_joints, e.tile_bytes,
+  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, n_pad, e.cfg.task.num_waypoints, e.cfg.task.variant, e.cfg.vehicle.n_joints, e.tile_bytes,
                      make_cold(e), e.blob, mask, obs, pad_only);
   return hipGetLastError();
 }
@@ -406,7 +406,9 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   const size_t n = size_t(cfg->num_envs), ts = cfg->dtype == AMENV_F64 ? 8 : 4;
   e->fbytes = size_t(e->nf) * n * ts;
   e->ibytes = size_t(AMENV_I_NFIELDS) * n * sizeof(int32_t);
-  e->n_tiles = int((n + 63) / 64);
+  // tiles are allocated in multiples of 4 (= 256 lanes, the largest workgroup): every launch geometry stays inside the blob and
+  // every padding lane holds a valid environment (initialised below), so kernels never need a per-lane bounds branch on the state
+  e->n_tiles = int((n + 255) / 256) * 4;
   e->tile_bytes = tile_bytes_for(e->nf, int(ts));
   e->blob_bytes = size_t(e->n_tiles) * e->tile_bytes;
   // latency regime (few waves per CU): one wave per workgroup spreads the waves over more CUs;

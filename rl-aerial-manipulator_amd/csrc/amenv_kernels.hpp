@@ -120,6 +120,7 @@ __device__ __forceinline__ void stage_obs(float* lds_row, const float* o) {
 // The block's region starts 16-B aligned (blockDim.x * OD * 4 bytes per block, blockDim.x a multiple of 64).
 template <int OD>
 __device__ __forceinline__ void flush_obs(const float* lds, float* __restrict__ obs_block, int rows_valid) {
+  if (rows_valid <= 0) return;   // a workgroup made only of padding lanes publishes nothing
   const float4* s = reinterpret_cast<const float4*>(lds);
   float4* d = reinterpret_cast<float4*>(obs_block);
   const int nflt = rows_valid * OD, nvec = nflt >> 2;
@@ -411,11 +412,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
 // WaypointQuadEnv.reset for masked envs (mask null = all) + observation of every env.
 // Launched over whole tiles: padding lanes (i >= n) are always reset so that they hold a valid state.
 template <typename T>
-__global__ void reset_kernel(int n, int K, int variant, int nj, uint32_t tile_bytes, const ColdParams C, void* __restrict__ blob,
+__global__ void reset_kernel(int n, int n_pad, int K, int variant, int nj, uint32_t tile_bytes, const ColdParams C, void* __restrict__ blob,
                              const uint8_t* __restrict__ mask, float* __restrict__ obs, int pad_only) {
   const bool v1 = variant != AMENV_TASK_V2_SCALED20;
   const int od = v1 ? 17 : 20 + 2 * nj;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;   // the blob holds n_pad / 64 tiles: nothing exists beyond the last padded lane
   const int lane = threadIdx.x & 63;
   const bool active = i < n;
   char* tile = const_cast<char*>(tile_base(blob, tile_bytes, i));
