@@ -244,12 +244,13 @@ const char* validate(const amenv_config* c) {
   if (c->vehicle.n_joints == 3 && (c->vehicle.n_rotors != 6 || c->task.num_waypoints != 1 || is_v1(c)))
     return "the arm vehicle is built for the 6-rotor airframe, the v2 task and 1 waypoint (BASELINE config 3)";
   if (c->vehicle.n_joints == 3 && c->dtype == AMENV_F64)
-    return "no fp64 build of the arm kernel: four inlined fp64 multibody RHS evaluations need more than the 512 registers of a "
-           "wavefront and the spilled build computed garbage on gfx950/ROCm 7.2 (DESIGN.md); the fp32 kernel is checked against the fp64 oracle";
+    return "no fp64 build of the arm kernel: four inlined fp64 multibody RHS evaluations exceed the 512 registers of a wavefront and "
+           "the spilled build computes garbage on gfx950/ROCm 7.2 (DESIGN.md); the fp32 arm kernel is checked against the fp64 oracle";
   if (c->task.variant != AMENV_TASK_V2_SCALED20 && !is_v1(c)) return "unknown task variant";
   if (is_v1(c) && c->task.num_waypoints > 2) return "v1 tasks draw 1..2 waypoints per episode: num_waypoints (storage bound) must be 1 or 2";
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
   if (c->task.max_episode_steps < 1 || c->task.counter_limit < 0) return "bad episode limits";
+  if (c->task.rk4_substeps < 0 || c->task.rk4_substeps > 64) return "rk4_substeps out of range";
   if (!(c->task.dt > 0.0) || !(c->vehicle.mass > 0.0)) return "dt and mass must be positive";
   for (int r = 0; r < c->vehicle.n_rotors; r++)
     if (std::fabs(c->vehicle.mix[r] - 1.0) > 1e-12) return "mix row 0 must be all ones: total thrust is the plain sum of rotor thrusts (quadcopter.py:111)";
@@ -275,11 +276,7 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
   if (T_steps > 0) {
-    if constexpr (NJ == 0) {   // the multi-step kernel is not instantiated for the arm vehicle (amenv_rollout refuses it)
-      hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C, AA);
-    } else {
-      return hipErrorNotSupported;
-    }
+    hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C, AA);
   } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
     hipExtLaunchKernelGGL((step_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward, io.done,
                           io.info, tl, P, C, AA);
@@ -520,9 +517,6 @@ int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, v
                   void* stream) {
   if (!e) return AMENV_ERR_INVALID;
   if (n_steps <= 0 || !actions) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: n_steps must be > 0 and actions non-NULL");
-  if (e->cfg.vehicle.n_joints != 0)
-    return fail(e, AMENV_ERR_INVALID, "amenv_rollout: not available for the arm vehicle (its multi-step kernel failed validation on gfx950: "
-                                      "it wrote outside its buffers); use amenv_step");
   if (!aligned16(actions) || (obs && !aligned16(obs))) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: actions/obs must be 16-byte aligned");
   DeviceGuard g(e->device);
   StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, nullptr, nullptr, nullptr, e->stats};

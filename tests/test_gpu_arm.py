@@ -131,23 +131,25 @@ def test_arm_momentum_conservation_on_gpu():
         env.close()
 
 
-def test_arm_vecenv_and_refused_rollout():
+def test_arm_rollout_equals_steps_and_vecenv():
     import torch
     import rl_aerial_manipulator_amd as amd
+    n, T = 300, 40
+    rng = np.random.RandomState(2)
+    a = np.stack([rand_actions(rng, n) for _ in range(T)])
+    a[:, ::7, 0] = 0.0
+    at = torch.from_numpy(a).cuda()
+    e1 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30); e2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30)
+    e1.reset(); e2.reset()
+    ro = e1.rollout(at)
+    assert ro["obs"].shape == (T, n, 26)
+    for t in range(T):
+        obs, rew, done, info = e2.step(at[t])
+        assert torch.equal(ro["obs"][t], obs) and torch.equal(ro["reward"][t], rew) and torch.equal(ro["info_bits"][t], info)
+    assert ro["done"].sum().item() > 0
     ve = amd.GpuVecEnv(num_envs=64, vehicle="hexa_arm")
     assert ve.observation_space.shape == (26,) and ve.action_space.shape == (7,)
     assert ve.reset().shape == (64, 26)
     o, r, d, inf = ve.step(np.tile(np.array([1, 0, 0, 0, 0.2, -0.2, 0.1], np.float32), (64, 1)))
     assert o.shape == (64, 26) and np.isfinite(o).all()
-    with pytest.raises(amd.AmenvError, match="not available for the arm vehicle"):
-        ve.backend.rollout(torch.zeros(4, 64, 7, device="cuda"))
-    # determinism of the step kernel: two envs, same seed, same actions -> bit-identical
-    rng = np.random.RandomState(2)
-    e1 = amd.GpuWaypointEnv(300, vehicle="hexa_arm", seed=3, max_episode_steps=30); e2 = amd.GpuWaypointEnv(300, vehicle="hexa_arm", seed=3, max_episode_steps=30)
-    assert torch.equal(e1.reset(), e2.reset())
-    for t in range(40):
-        a = torch.from_numpy(rand_actions(rng, 300)).cuda()
-        o1, r1, d1, i1 = e1.step(a); o2, r2, d2, i2 = e2.step(a)
-        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(i1, i2)
-    assert e1.stats()["episodes"] == e2.stats()["episodes"] > 0
     e1.close(); e2.close(); ve.close()
