@@ -14,6 +14,8 @@
 //           b_k = w x (w x r_k) + 2 w x u_k + a_k,  W_k = w + w_k;  solved as  I_c wd = n - S x f / mtot  with the
 //           composite inertia about the system CoM  I_c = I_O - (|S|^2 1 - S S^T)/mtot,  then A = (f + S x wd)/mtot.
 #pragma once
+#include <type_traits>
+
 #include "amenv_model.hpp"
 
 namespace amenv_dev {
@@ -28,7 +30,14 @@ struct ArmParams {
   T kp, kd, amax;
   T mtot, inv_mtot;
   float mid[3], half[3];  // joint command = fmaf(action, half, mid), formed in fp32
+  int32_t generic_axes;   // 0: joint axes are (z, x, x) -> AxesZXX fast path; 1: general axes
 };
+
+// Joint-axis pattern of an instantiation: 0/1/2 = the joint axis is +x/+y/+z (compile time, so R's columns are picked by constant
+// index), -1 = general axis (Rodrigues).  The repo's arm is <2, 0, 0> (manipulator.sdf:103,163,237).
+template <int A0, int A1, int A2> struct Axes { static constexpr int code[3] = {A0, A1, A2}; };
+using AxesZXX = Axes<2, 0, 0>;
+using AxesAny = Axes<-1, -1, -1>;
 
 template <typename T> struct V3 { T x, y, z; };
 template <typename T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -69,8 +78,22 @@ __device__ __forceinline__ M3<T> rodrigues(V3<T> a, T th) {   // rotation by th 
   return R;
 }
 
+// R <- R * Rot(axis c, th) for a coordinate axis: only the two other columns mix (12 FMAs instead of Rodrigues + a 3x3 product)
+template <int c, typename T>
+__device__ __forceinline__ void rotate_about_column(M3<T>& R, T th) {
+  T s, co;
+  sincos_(th, s, co);
+  constexpr int a = c == 0 ? 1 : (c == 1 ? 2 : 0), b = c == 0 ? 2 : (c == 1 ? 0 : 1);   // (a, b, c) is a cyclic permutation
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const T ra = R.m[3 * i + a], rb = R.m[3 * i + b];
+    R.m[3 * i + a] = fma_(co, ra, s * rb);
+    R.m[3 * i + b] = fma_(co, rb, -(s * ra));
+  }
+}
+
 // 19 derivatives of the arm vehicle.  y: state, F / M: rotor wrench after the mixer, cmd: joint position commands.
-template <typename T, typename PT>
+template <typename T, typename AX, typename PT>
 __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
   const V3<T> om{y[10], y[11], y[12]};
   // rotation of the normalised quaternion (body -> world is its transpose, as in the rigid model)
@@ -94,39 +117,49 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   // chain kinematics relative to the body frame
   M3<T> R{{T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}};
   V3<T> p{T(0), T(0), T(0)}, pd = p, pdd = p, w = p, al = p;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
+  // (compile-time recursion over the joints so each joint's axis code is a constant)
+  auto joint = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int ac = AX::code[k];
     const V3<T> o{A.jo[k][0], A.jo[k][1], A.jo[k][2]}, ax{A.ja[k][0], A.ja[k][1], A.ja[k][2]};
     const V3<T> Ro = mul(R, o);
     const V3<T> wRo = cross(w, Ro);
     pd = pd + wRo;
     pdd = pdd + cross(al, Ro) + cross(w, wRo);
     p = p + Ro;
-    const V3<T> z = mul(R, ax);
+    V3<T> z;
+    if constexpr (ac >= 0) z = V3<T>{R.m[ac], R.m[3 + ac], R.m[6 + ac]};      // R e_c = column c of R
+    else z = mul(R, ax);
     al = al + thdd[k] * z + y[16 + k] * cross(w, z);
     w = w + y[16 + k] * z;
-    R = mul(R, rodrigues(ax, y[13 + k]));
+    if constexpr (ac >= 0) rotate_about_column<ac>(R, y[13 + k]);
+    else R = mul(R, rodrigues(ax, y[13 + k]));
     const V3<T> Rc = mul(R, V3<T>{A.lc[k][0], A.lc[k][1], A.lc[k][2]});
     const V3<T> wRc = cross(w, Rc);
     const V3<T> r = p + Rc, u = pd + wRc, a_ = pdd + cross(al, Rc) + cross(w, wRc);
     const T m = A.lm[k];
     const V3<T> b = cross(om, cross(om, r)) + T(2) * cross(om, u) + a_;
-    // rotational terms in the LINK frame: J x = R (I (R^T x))
+    // link inertia in body axes, once: J = R I R^T (symmetric, 6 entries); every rotational term and I_O use it
     const M3<T> Ik{{A.li[k][0], A.li[k][1], A.li[k][2], A.li[k][1], A.li[k][3], A.li[k][4], A.li[k][2], A.li[k][4], A.li[k][5]}};
+    const M3<T> RI = mul(R, Ik);
+    const T Jxx = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[0], R.m[1], R.m[2]), Jxy = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[3], R.m[4], R.m[5]);
+    const T Jxz = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[6], R.m[7], R.m[8]), Jyy = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[3], R.m[4], R.m[5]);
+    const T Jyz = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[6], R.m[7], R.m[8]), Jzz = dot3_(RI.m[6], RI.m[7], RI.m[8], R.m[6], R.m[7], R.m[8]);
+    const M3<T> J{{Jxx, Jxy, Jxz, Jxy, Jyy, Jyz, Jxz, Jyz, Jzz}};
     const V3<T> aa = al + cross(om, w), Om = om + w;
-    const V3<T> Jaa = mul(R, mul(Ik, mulT(R, aa))), JOm = mul(R, mul(Ik, mulT(R, Om)));
+    const V3<T> Jaa = mul(J, aa), JOm = mul(J, Om);
     S = S + m * r; fb = fb + m * b;
     nb = nb + m * cross(r, b) + Jaa + cross(Om, JOm);
-    // I_O += R I R^T + m (|r|^2 1 - r r^T)   (symmetric: 6 entries)
-    const M3<T> RI = mul(R, Ik);
+    // I_O += J + m (|r|^2 1 - r r^T)
     const T r2 = dot(r, r);
-    IO[0] += dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[0], R.m[1], R.m[2]) + m * (r2 - r.x * r.x);
-    IO[1] += dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[3], R.m[4], R.m[5]) - m * (r.x * r.y);
-    IO[2] += dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[6], R.m[7], R.m[8]) - m * (r.x * r.z);
-    IO[3] += dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[3], R.m[4], R.m[5]) + m * (r2 - r.y * r.y);
-    IO[4] += dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[6], R.m[7], R.m[8]) - m * (r.y * r.z);
-    IO[5] += dot3_(RI.m[6], RI.m[7], RI.m[8], R.m[6], R.m[7], R.m[8]) + m * (r2 - r.z * r.z);
-  }
+    IO[0] += Jxx + m * (r2 - r.x * r.x);
+    IO[1] += Jxy - m * (r.x * r.y);
+    IO[2] += Jxz - m * (r.x * r.z);
+    IO[3] += Jyy + m * (r2 - r.y * r.y);
+    IO[4] += Jyz - m * (r.y * r.z);
+    IO[5] += Jzz + m * (r2 - r.z * r.z);
+  };
+  joint(std::integral_constant<int, 0>{}); joint(std::integral_constant<int, 1>{}); joint(std::integral_constant<int, 2>{});
   // external wrench about O: rotor thrust / moments, gravity at every CoM
   V3<T> f = A.mtot * gb - fb;
   f.z += F;
@@ -155,13 +188,13 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   for (int k = 0; k < 3; k++) { d[13 + k] = y[16 + k]; d[16 + k] = thdd[k]; }
 }
 
-template <typename T, typename PT>
+template <typename AX, typename T, typename PT>
 __device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
-  arm_rhs_body<T>(P, A, y, F, M, cmd, d);
+  arm_rhs_body<T, AX>(P, A, y, F, M, cmd, d);
 }
 
 // One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states.
-template <typename T, int NROT, int KW>
+template <typename T, int NROT, int KW, typename AX>
 __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act) {
   const float Ff = (act[0] * P.mass_f) * P.g_f;
   const T u0 = T(Ff), u1 = T(act[1] * P.mscale_f), u2 = T(act[2] * P.mscale_f), u3 = T(act[3] * P.mscale_f);
@@ -184,16 +217,16 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
     // RK4 with a running weighted sum (acc = k1 + 2 k2 + 2 k3 + k4): four 19-vectors live instead of six -- the fp64
     // build of this kernel otherwise needs more than the 512 registers a wave can have
     T k[19], acc[19], s[19];
-    arm_rhs(P, A, y, F, M, cmd, k);
+    arm_rhs<AX>(P, A, y, F, M, cmd, k);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = k[i]; s[i] = fma_(hh, k[i], y[i]); }
-    arm_rhs(P, A, s, F, M, cmd, k);
+    arm_rhs<AX>(P, A, s, F, M, cmd, k);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(hh, k[i], y[i]); }
-    arm_rhs(P, A, s, F, M, cmd, k);
+    arm_rhs<AX>(P, A, s, F, M, cmd, k);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(h, k[i], y[i]); }
-    arm_rhs(P, A, s, F, M, cmd, k);
+    arm_rhs<AX>(P, A, s, F, M, cmd, k);
 #pragma unroll
     for (int i = 0; i < 19; i++) y[i] = fma_(h6, acc[i] + k[i], y[i]);
   } while (++it < P.substeps);

@@ -212,8 +212,11 @@ ArmParams<T> make_arm(const amenv& e) {
     A.li[k][0] = T(I[0]); A.li[k][1] = T(I[1]); A.li[k][2] = T(I[2]); A.li[k][3] = T(I[4]); A.li[k][4] = T(I[5]); A.li[k][5] = T(I[8]);
     const float lo = float(v.joint_limit[2 * k]), hi = float(v.joint_limit[2 * k + 1]);
     A.half[k] = 0.5f * (hi - lo); A.mid[k] = 0.5f * (hi + lo);
+
   }
   A.kp = T(v.joint_kp); A.kd = T(v.joint_kd); A.amax = T(v.joint_acc_max);
+  const double zxx[9] = {0, 0, 1, 1, 0, 0, 1, 0, 0};
+  A.generic_axes = std::memcmp(v.joint_axis, zxx, sizeof(zxx)) == 0 ? 0 : 1;
   A.mtot = T(v.mass); A.inv_mtot = T(1.0 / v.mass);
   return A;
 }

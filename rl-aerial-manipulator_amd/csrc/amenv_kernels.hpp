@@ -217,7 +217,10 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
                                               bool have_episode, bool& was_reset, int& ep_len_out, float& ep_ret_out) {
   constexpr int OD = ObsDim<VAR, NJ>::value;
   const int K = KW == 1 ? 1 : P.K;
-  if constexpr (NJ > 0) { dynamics_arm<T, NROT, KW>(P, AA.p, e, act); } else { dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]); }
+  if constexpr (NJ > 0) {
+    if (AA.p.generic_axes) dynamics_arm<T, NROT, KW, AxesAny>(P, AA.p, e, act);   // wave-uniform: one of the two bodies runs
+    else dynamics_arm<T, NROT, KW, AxesZXX>(P, AA.p, e, act);
+  } else { dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]); }
   uint32_t bits;
   if constexpr (VAR == VAR_V1) { bits = task_step_v1<T, KW>(P, e, reward); } else { bits = task_step<T, KW>(P, e, reward); }
   e.ep_return += reward;

@@ -24,8 +24,9 @@ def child(args):
         env = amd.GpuWaypointEnv(n, vehicle=args.vehicle, seed=0, block_size=args.block_size)
         env.reset()
         g = torch.Generator(device="cuda").manual_seed(1)
-        ring = torch.randn(64, n, 4, device="cuda", generator=g) * (0.1 if args.ring == "random" else 0.0)
+        ring = torch.randn(64, n, env.act_dim, device="cuda", generator=g) * (0.1 if args.ring == "random" else 0.0)
         ring[..., 0] += 1.0
+        ring[..., 4:] *= 3.0
         ring = ring.clamp(min=-1, max=2).contiguous()
         for t in range(64):
             env.step(ring[t])

@@ -20,8 +20,9 @@ import rl_aerial_manipulator_amd as amd
 env = amd.GpuWaypointEnv(a.envs, vehicle=a.vehicle, seed=0, block_size=a.block_size)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(1)
-ring = torch.randn(16, a.envs, 4, device="cuda", generator=g) * 0.1
+ring = torch.randn(16, a.envs, env.act_dim, device="cuda", generator=g) * 0.1
 ring[..., 0] += 1.0
+ring[..., 4:] *= 3.0
 ring = ring.clamp(min=-1, max=2).contiguous()
 for t in range(a.steps):
     env.step(ring[t % 16])

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--vehicle", default="hexa")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
     a = ap.parse_args()
+    a.out = os.path.abspath(a.out)   # rocprofv3 runs with cwd=/tmp
     os.makedirs(a.out, exist_ok=True)
     res = {}
     for n in a.envs:

@@ -26,8 +26,9 @@ env.reset()
 lib = C.CDLL(amd._lib.LIB_PATH)
 lib.amenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 g = torch.Generator(device="cuda").manual_seed(1)
-ring = torch.randn(16, a.envs, 4, device="cuda", generator=g) * (0.0 if a.hover else 0.1)
+ring = torch.randn(16, a.envs, env.act_dim, device="cuda", generator=g) * (0.0 if a.hover else 0.1)
 ring[..., 0] += 1.0
+ring[..., 4:] *= 3.0
 ring = ring.clamp(min=-1, max=2).contiguous()
 names = ["entry->loads issued", "loads issued->landed", "compute (mixer+RK4+task+obs)", "state/output stores issued", "LDS stage+barrier+obs flush",
          "stats", "drain stores (vmcnt 0)"]
