@@ -1,0 +1,47 @@
+"""The reference's training entry (initial-implementation-v2/rl_train.py:22-64) on the GPU-resident stack.
+
+    python examples/rl_train_gpu.py [--envs 4096] [--timesteps 4100000] [--resume ppo_model_2300000_steps.zip]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/rl_train_gpu.py ...
+
+Same hyper-parameters as the reference (lr 2e-4, 12 epochs, gamma .995, lambda .9, clip .2, ent 5e-4 -- 1e-4 when resuming,
+:35 -- MLP [128,64,64] tanh); the rollout is `envs x n_steps` instead of `8 x 2048`, so n_steps / batch_size are rescaled to
+keep the reference's 16,384-sample rollouts x 128-sample minibatches ratio (128 minibatches per epoch).
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--n-steps", type=int, default=128)
+    ap.add_argument("--timesteps", type=int, default=4_100_000)          # rl_train.py:56
+    ap.add_argument("--resume", default=None, help="SB3 zip / policy.pth to start from (rl_train.py:33-35)")
+    ap.add_argument("--save", default="waypoint_controller_gpu")         # rl_train.py:57
+    ap.add_argument("--vehicle", default="quad")
+    a = ap.parse_args()
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    from rl_aerial_manipulator_amd import sharding
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    sh = sharding.shard_from_env(a.envs)
+    dist = sharding.init_process_group("nccl", torch.device("cuda", local))
+    env = amd.GpuWaypointEnv(a.envs, device=local, vehicle=a.vehicle, seed=0, env_id_offset=sh.env_id_offset)
+    model = amd.PPO(env, learning_rate=2e-4, n_steps=a.n_steps, batch_size=a.envs * a.n_steps // 128, n_epochs=12, gamma=0.995,
+                    gae_lambda=0.9, clip_range=0.2, ent_coef=1e-4 if a.resume else 5e-4, dist=dist)
+    if a.resume:
+        model.load_policy(a.resume)
+    show = (lambda r: print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)) if sh.rank == 0 else None
+    model.learn(a.timesteps, log_fn=show)
+    if sh.rank == 0:
+        print("saved", model.save(a.save))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -269,6 +269,21 @@ int amenv_obsnorm_apply(amenv_obsnorm* h, const float* in, float* out, int64_t n
 int amenv_obsnorm_get(amenv_obsnorm* h, double* mean, double* var, double* count, void* stream);
 int amenv_obsnorm_set(amenv_obsnorm* h, const double* mean, const double* var, double count, void* stream);
 
+/* ---- GPU-resident PPO helpers (SURVEY 8 row f3 / BASELINE config 5) ---------------------------------------------------
+ * The reference trains with SB3 PPO (v2/rl_train.py:38-56).  The MLP stays in PyTorch-ROCm; these two entry points are
+ * the per-env elementwise pieces of SB3's loop, on caller-owned device buffers of the CURRENT device.
+ *
+ * amenv_gae: RolloutBuffer.compute_returns_and_advantage (SB3 2.6.0) over time-major [n_steps, n_envs] f32 buffers;
+ * dones[t, i] != 0 = env i's episode ended at step t (SB3's episode_starts shifted by one; the last row is its `dones`
+ * argument); last_values[i] = V(obs after the last step).  gamma = .995, gae_lambda = .9 in the reference (:46-47). */
+int amenv_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, float* advantages,
+              float* returns, int32_t n_steps, int64_t n_envs, float gamma, float gae_lambda, void* stream);
+/* DiagGaussianDistribution.sample + log_prob + the action-space clip of collect_rollouts: raw = mean + exp(log_std) z,
+ * clipped = clip(raw, low, high) (bounds v2/rl_env_scaledObs.py:20-24), logp = log N(raw; mean, exp(log_std)) summed over
+ * act_dim (4 or 7).  z from Philox4x32-10 keyed by (seed, env_id_offset + i, draw): pass a different `draw` per call. */
+int amenv_gaussian_act(const float* mean, const float* log_std, const float* low, const float* high, float* raw, float* clipped,
+                       float* logp, int64_t n_envs, int32_t act_dim, uint64_t seed, uint32_t draw, int64_t env_id_offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

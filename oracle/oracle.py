@@ -194,3 +194,20 @@ def philox(seed, gid, episode, block):
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+def gae_reference(rewards, values, dones, last_values, gamma, gae_lambda):
+    """numpy restatement of SB3 2.6.0 `RolloutBuffer.compute_returns_and_advantage` (third-party; the reference reaches
+    it through `PPO.learn`, v2/rl_train.py:56) in float64 on time-major [T, N] arrays.  `dones[t]` = episode ended at step
+    t, i.e. SB3's `episode_starts[t + 1]` and, for the last row, its `dones` argument."""
+    r, v = np.asarray(rewards, np.float64), np.asarray(values, np.float64)
+    nnt = 1.0 - (np.asarray(dones) != 0).astype(np.float64)
+    T = r.shape[0]
+    adv = np.zeros_like(r)
+    last, next_v = np.zeros(r.shape[1]), np.asarray(last_values, np.float64)
+    for t in reversed(range(T)):
+        delta = r[t] + gamma * next_v * nnt[t] - v[t]
+        last = delta + gamma * gae_lambda * nnt[t] * last
+        adv[t] = last
+        next_v = v[t]
+    return adv, adv + v

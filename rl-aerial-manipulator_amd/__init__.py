@@ -12,5 +12,7 @@ from . import vec_env
 from .gpu_env import GpuWaypointEnv
 from .vec_env import GpuVecEnv
 from .obs_norm import GpuVecNormalize, ObsNormalizer
+from . import ppo
+from .ppo import PPO, ActorCritic
 
-__all__ = ["GpuWaypointEnv", "GpuVecEnv", "GpuVecNormalize", "ObsNormalizer", "vec_env", "AmenvError", "_lib", "sharding"]
+__all__ = ["GpuWaypointEnv", "GpuVecEnv", "GpuVecNormalize", "ObsNormalizer", "PPO", "ActorCritic", "ppo", "vec_env", "AmenvError", "_lib", "sharding"]

@@ -13,6 +13,7 @@
 
 #include "amenv_kernels.hpp"
 #include "amenv_obsnorm.hpp"
+#include "amenv_train.hpp"
 
 using namespace amenv_dev;
 
@@ -647,6 +648,32 @@ int amenv_obsnorm_set(amenv_obsnorm* h, const double* mean, const double* var, d
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(h->buf, staging.data(), staging.size(), hipMemcpyHostToDevice) != hipSuccess)
     return AMENV_ERR_HIP;
   return AMENV_OK;
+}
+
+// ---- PPO helpers (row f3): GAE over a [T, N] rollout buffer, Gaussian action sampling ------------------------------
+int amenv_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, float* advantages,
+              float* returns, int32_t n_steps, int64_t n_envs, float gamma, float gae_lambda, void* stream) {
+  if (!rewards || !values || !dones || !last_values || !advantages || !returns || n_steps <= 0 || n_envs <= 0 ||
+      !(gamma >= 0.0f && gamma <= 1.0f) || !(gae_lambda >= 0.0f && gae_lambda <= 1.0f))
+    return AMENV_ERR_INVALID;
+  const int bs = n_envs <= 65536 ? 64 : 256;
+  hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((n_envs + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream, rewards, values, dones,
+                     last_values, advantages, returns, (int)n_steps, (int64_t)n_envs, gamma, gae_lambda);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+int amenv_gaussian_act(const float* mean, const float* log_std, const float* low, const float* high, float* raw, float* clipped,
+                       float* logp, int64_t n_envs, int32_t act_dim, uint64_t seed, uint32_t draw, int64_t env_id_offset, void* stream) {
+  if (!mean || !log_std || !low || !high || !raw || !clipped || !logp || n_envs <= 0 || env_id_offset < 0) return AMENV_ERR_INVALID;
+  const int bs = n_envs <= 65536 ? 64 : 256;
+  const dim3 grid((unsigned)((n_envs + bs - 1) / bs)), block(bs);
+  const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+  switch (act_dim) {
+    case 4: hipLaunchKernelGGL(gaussian_act_kernel<4>, grid, block, 0, (hipStream_t)stream, mean, log_std, low, high, raw, clipped, logp, (int64_t)n_envs, s_lo, s_hi, draw, (int64_t)env_id_offset); break;
+    case 7: hipLaunchKernelGGL(gaussian_act_kernel<7>, grid, block, 0, (hipStream_t)stream, mean, log_std, low, high, raw, clipped, logp, (int64_t)n_envs, s_lo, s_hi, draw, (int64_t)env_id_offset); break;
+    default: return AMENV_ERR_INVALID;   // 4 = quad/hexa, 7 = hexa + 3 joints
+  }
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 
 #ifdef AMENV_STAMPS

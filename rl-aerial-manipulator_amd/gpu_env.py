@@ -117,6 +117,23 @@ class GpuWaypointEnv:
                     "amenv_step")
         return self.obs, self.reward, self.done, self.info_bits
 
+    def step_into(self, actions, obs, reward, done):
+        """step() writing obs [N,obs_dim] f32, reward [N], done [N] u8 straight into caller tensors (e.g. rows of a rollout
+        buffer) instead of the persistent output buffers; info_bits / terminal_obs / ep_return / ep_len as in step()."""
+        a = self._actions(actions)
+        n = self.num_envs
+        ok = (obs.device == self.device and obs.dtype == torch.float32 and obs.is_contiguous() and tuple(obs.shape) == (n, self.obs_dim)
+              and reward.device == self.device and reward.dtype == self.state_dtype and reward.is_contiguous() and reward.numel() == n
+              and done.device == self.device and done.dtype == torch.uint8 and done.is_contiguous() and done.numel() == n)
+        if not ok:
+            raise L.AmenvError("step_into: obs/reward/done must be contiguous tensors of this env's device, dtype and shape")
+        self._check(self.lib.amenv_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(obs.data_ptr()),
+                                        C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()),
+                                        C.c_void_p(self.info_bits.data_ptr()), C.c_void_p(self.terminal_obs.data_ptr()),
+                                        C.c_void_p(self.ep_return.data_ptr()), C.c_void_p(self.ep_len.data_ptr()), self._stream()),
+                    "amenv_step")
+        return obs, reward, done, self.info_bits
+
     def step_timed(self, actions):
         """step() that also returns the device-side duration (us) of that one kernel launch (synchronises)."""
         a = self._actions(actions)

@@ -1,0 +1,382 @@
+"""GPU-resident PPO over `GpuWaypointEnv` (BASELINE config 5).
+
+Mirrors what the reference's training entry does through Stable-Baselines3 (v2/rl_train.py:22-56):
+`PPO("MlpPolicy", env, learning_rate=2e-4, n_steps=2048, batch_size=128, n_epochs=12, gamma=.995, gae_lambda=.9,
+clip_range=.2, ent_coef=5e-4, policy_kwargs=dict(net_arch=[128,64,64], activation_fn=nn.Tanh))` and SB3's defaults
+(vf_coef .5, max_grad_norm .5, normalize_advantage, Adam eps 1e-5, orthogonal init; values read from the `data` JSON of
+`checkpoints_from_8_6M/ppo_model_2300000_steps.zip`).  SB3 2.6.0 is third-party and absent here: its published algorithm is
+restated, **parity unpinned** except for the policy network itself, whose tensors load from the reference's `policy.pth`
+(tests: the reference's best checkpoint flies the waypoint task on this env).
+
+What runs where:
+  * env step, GAE (`amenv_gae`), action sampling + log-prob + clip (`amenv_gaussian_act`): HIP kernels behind the C ABI;
+  * the two 20->128->64->64 tanh MLPs, their backward and Adam: PyTorch-ROCm (rocBLAS GEMMs) -- plumbing, as SURVEY §1 says;
+  * the whole rollout stays in HBM: the env writes obs / reward / done straight into rows of the rollout buffer;
+  * multi-GPU: one process per GPU, envs sharded by global id, ONE all-reduce per minibatch of one flat fp32 gradient buffer
+    (30,537 parameters = 122 KB for the 20-D / 4-D task) over RCCL; nothing on the step path.
+"""
+import ctypes as C
+import io
+import json
+import math
+import zipfile
+
+import torch
+from torch import nn
+
+from . import _lib as L
+
+
+def _mlp(sizes):
+    layers = []
+    for a, b in zip(sizes[:-1], sizes[1:]):
+        layers += [nn.Linear(a, b), nn.Tanh()]
+    return nn.Sequential(*layers)
+
+
+class _MlpExtractor(nn.Module):
+    """Separate actor / critic trunks; attribute names give SB3's state-dict keys `mlp_extractor.policy_net.{0,2,4}.*`."""
+
+    def __init__(self, obs_dim, net_arch):
+        super().__init__()
+        self.policy_net = _mlp([obs_dim, *net_arch])
+        self.value_net = _mlp([obs_dim, *net_arch])
+
+
+class ActorCritic(nn.Module):
+    """SB3 `ActorCriticPolicy` for a Box action space: tanh MLP [128,64,64] x2, linear heads, state-independent log_std
+    (v2/rl_train.py:27-30).  `state_dict()` has exactly the keys and shapes of the reference checkpoints' `policy.pth`."""
+
+    def __init__(self, obs_dim=20, act_dim=4, net_arch=(128, 64, 64), log_std_init=0.0, ortho_init=True,
+                 action_low=None, action_high=None):
+        super().__init__()
+        self.obs_dim, self.act_dim, self.net_arch = int(obs_dim), int(act_dim), tuple(net_arch)
+        self.log_std = nn.Parameter(torch.full((self.act_dim,), float(log_std_init)))
+        self.mlp_extractor = _MlpExtractor(self.obs_dim, self.net_arch)
+        self.action_net = nn.Linear(self.net_arch[-1], self.act_dim)
+        self.value_net = nn.Linear(self.net_arch[-1], 1)
+        # action space of WaypointQuadEnv (v2/rl_env_scaledObs.py:20-24); joint commands of the arm are in [-1, 1] too
+        lo = [0.0] + [-1.0] * (self.act_dim - 1) if action_low is None else action_low
+        hi = [2.0] + [1.0] * (self.act_dim - 1) if action_high is None else action_high
+        self.register_buffer("action_low", torch.as_tensor(lo, dtype=torch.float32), persistent=False)
+        self.register_buffer("action_high", torch.as_tensor(hi, dtype=torch.float32), persistent=False)
+        if ortho_init:  # SB3: gain sqrt(2) for the trunks, 0.01 for the action head, 1 for the value head
+            for mod, gain in ((self.mlp_extractor, math.sqrt(2.0)), (self.action_net, 0.01), (self.value_net, 1.0)):
+                for m in mod.modules():
+                    if isinstance(m, nn.Linear):
+                        nn.init.orthogonal_(m.weight, gain=gain)
+                        nn.init.zeros_(m.bias)
+        self.flat_param = self.flat_grad = None
+
+    # ---- forward pieces -----------------------------------------------------------------------
+    def actor(self, obs):
+        return self.action_net(self.mlp_extractor.policy_net(obs))
+
+    def critic(self, obs):
+        return self.value_net(self.mlp_extractor.value_net(obs)).squeeze(-1)
+
+    def evaluate_actions(self, obs, actions):
+        """values, log pi(a|s), entropy -- SB3 ActorCriticPolicy.evaluate_actions for DiagGaussianDistribution."""
+        mean = self.actor(obs)
+        z = (actions - mean) * torch.exp(-self.log_std)
+        logp = (-0.5 * z * z - self.log_std - 0.5 * math.log(2.0 * math.pi)).sum(-1)
+        entropy = (0.5 + 0.5 * math.log(2.0 * math.pi) + self.log_std).sum().expand(obs.shape[0])
+        return self.critic(obs), logp, entropy
+
+    @torch.no_grad()
+    def predict(self, obs, deterministic=True, generator=None):
+        """Action for the env: mean (or a sample) clipped to the action space, as SB3's `policy.predict`."""
+        mean = self.actor(obs)
+        if not deterministic:
+            mean = mean + torch.exp(self.log_std) * torch.randn(mean.shape, device=mean.device, generator=generator)
+        return torch.minimum(torch.maximum(mean, self.action_low), self.action_high)
+
+    # ---- one flat parameter / gradient buffer ---------------------------------------------------
+    def flatten_(self):
+        """Re-home every parameter (and its gradient) as a view into ONE flat fp32 buffer: the optimiser updates one
+        tensor and the multi-GPU gradient exchange is one all-reduce of `flat_grad`."""
+        ps = list(self.parameters())
+        n = sum(p.numel() for p in ps)
+        flat = torch.empty(n, dtype=ps[0].dtype, device=ps[0].device)
+        grad = torch.zeros_like(flat)
+        off = 0
+        for p in ps:
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + k].view_as(p)
+            p.grad = grad[off:off + k].view_as(p)
+            off += k
+        self.flat_param, self.flat_grad = flat, grad
+        return self
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters())
+
+    # ---- SB3 checkpoint tensors -------------------------------------------------------------------
+    @staticmethod
+    def read_sb3_state_dict(path):
+        """Tensors of an SB3 checkpoint: a `.zip` as `PPO.save` writes (v2/rl_train.py:57, `policy.pth` inside) or a bare
+        `policy.pth`.  Loaded with `weights_only=True`: nothing from the file is executed."""
+        if zipfile.is_zipfile(path):
+            with zipfile.ZipFile(path) as z:
+                names = z.namelist()
+                if "policy.pth" in names:
+                    return torch.load(io.BytesIO(z.read("policy.pth")), weights_only=True, map_location="cpu")
+        return torch.load(path, weights_only=True, map_location="cpu")
+
+    @classmethod
+    def from_sb3(cls, path_or_state_dict, device="cpu"):
+        sd = path_or_state_dict if isinstance(path_or_state_dict, dict) else cls.read_sb3_state_dict(path_or_state_dict)
+        w0 = sd["mlp_extractor.policy_net.0.weight"]
+        arch = tuple(int(sd[f"mlp_extractor.policy_net.{i}.weight"].shape[0]) for i in range(0, 64, 2)
+                     if f"mlp_extractor.policy_net.{i}.weight" in sd)
+        pol = cls(obs_dim=int(w0.shape[1]), act_dim=int(sd["action_net.weight"].shape[0]), net_arch=arch, ortho_init=False)
+        pol.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+        return pol.to(device)
+
+    def save_sb3_policy(self, path):
+        """Write `policy.pth` with SB3's key names: `model.policy.load_state_dict(torch.load(path))` accepts it."""
+        torch.save({k: v.detach().cpu().clone() for k, v in self.state_dict().items()}, path)
+
+
+class RolloutBuffer:
+    """Time-major rollout storage in HBM: obs [T+1, N, D] (row T = the observation after the last step), raw actions
+    [T, N, A], log-probs / values / rewards / advantages / returns [T, N] f32, dones [T, N] u8 (episode ended AT step t)."""
+
+    def __init__(self, n_steps, n_envs, obs_dim, act_dim, device):
+        T, N = int(n_steps), int(n_envs)
+        f = dict(dtype=torch.float32, device=device)
+        self.n_steps, self.n_envs = T, N
+        self.obs = torch.zeros(T + 1, N, obs_dim, **f)
+        self.actions = torch.zeros(T, N, act_dim, **f)
+        self.logp = torch.zeros(T, N, **f)
+        self.values = torch.zeros(T, N, **f)
+        self.rewards = torch.zeros(T, N, **f)
+        self.dones = torch.zeros(T, N, dtype=torch.uint8, device=device)
+        self.last_values = torch.zeros(N, **f)
+        self.advantages = torch.zeros(T, N, **f)
+        self.returns = torch.zeros(T, N, **f)
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in vars(self).values() if torch.is_tensor(t))
+
+
+def compute_gae(buffer, gamma, gae_lambda):
+    """advantages / returns of a rollout buffer through the HIP kernel (`amenv_gae`); device tensors only."""
+    b = buffer
+    if not b.rewards.is_cuda:
+        raise L.AmenvError("compute_gae runs on the GPU only (amenv_gae); there is no CPU fallback")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = L.load().amenv_gae(p(b.rewards), p(b.values), p(b.dones), p(b.last_values), p(b.advantages), p(b.returns),
+                            b.n_steps, b.n_envs, float(gamma), float(gae_lambda),
+                            C.c_void_p(torch.cuda.current_stream(b.rewards.device).cuda_stream))
+    if rc != 0:
+        raise L.AmenvError(f"amenv_gae failed ({rc})")
+    return b.advantages, b.returns
+
+
+def gaussian_act(mean, log_std, low, high, raw_out, clipped_out, logp_out, seed, draw, env_id_offset=0):
+    """Sample + log-prob + clip in one launch (`amenv_gaussian_act`); noise keyed by (seed, global env id, draw)."""
+    if not mean.is_cuda:
+        raise L.AmenvError("gaussian_act runs on the GPU only (amenv_gaussian_act); there is no CPU fallback")
+    n, a = mean.shape
+    for t in (mean, raw_out, clipped_out, logp_out, log_std, low, high):
+        if not (t.is_contiguous() and t.dtype == torch.float32 and t.device == mean.device):
+            raise L.AmenvError("gaussian_act: contiguous float32 tensors on one device required")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = L.load().amenv_gaussian_act(p(mean), p(log_std), p(low), p(high), p(raw_out), p(clipped_out), p(logp_out), n, a,
+                                     int(seed) & 0xFFFFFFFFFFFFFFFF, int(draw) & 0xFFFFFFFF, int(env_id_offset),
+                                     C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream))
+    if rc != 0:
+        raise L.AmenvError(f"amenv_gaussian_act failed ({rc}): act_dim must be 4 or 7")
+
+
+def ppo_update(policy, optimizer, obs, actions, old_logp, advantages, returns, *, batch_size, n_epochs, clip_range=0.2,
+               ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5, normalize_advantage=True, generator=None, dist=None):
+    """SB3 `PPO.train()` on flattened rollout tensors (obs [n, D], actions [n, A], the rest [n]).  Device-agnostic torch;
+    with `dist` (an initialised torch.distributed, RCCL on GPUs) every minibatch gradient is averaged over ranks with ONE
+    all-reduce of the policy's flat gradient buffer.  Returns the mean losses of the last epoch (one host sync)."""
+    n = obs.shape[0]
+    world = dist.get_world_size() if dist is not None else 1
+    if policy.flat_grad is None:
+        policy.flatten_()
+    stats = torch.zeros(5, device=obs.device)
+    n_batches = 0
+    for epoch in range(n_epochs):
+        perm = torch.randperm(n, device=obs.device, generator=generator)
+        if epoch == n_epochs - 1:
+            stats.zero_()
+            n_batches = 0
+        for start in range(0, n, batch_size):
+            idx = perm[start:start + batch_size]
+            adv = advantages[idx]
+            if normalize_advantage and adv.numel() > 1:
+                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+            values, logp, entropy = policy.evaluate_actions(obs[idx], actions[idx])
+            ratio = torch.exp(logp - old_logp[idx])
+            pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1.0 - clip_range, 1.0 + clip_range)).mean()
+            vl = torch.nn.functional.mse_loss(returns[idx], values)
+            el = -entropy.mean()
+            loss = pl + ent_coef * el + vf_coef * vl
+            policy.flat_grad.zero_()
+            loss.backward()
+            if world > 1:
+                dist.all_reduce(policy.flat_grad)
+                policy.flat_grad.div_(world)
+            gn = policy.flat_grad.norm(2)
+            if max_grad_norm is not None:
+                policy.flat_grad.mul_(torch.clamp(max_grad_norm / (gn + 1e-6), max=1.0))
+            optimizer.step()
+            with torch.no_grad():
+                stats += torch.stack([pl.detach(), vl.detach(), el.detach(), ((ratio.detach() - 1.0).abs() > clip_range).float().mean(), gn])
+            n_batches += 1
+    s = (stats / max(n_batches, 1)).tolist()
+    return dict(policy_loss=s[0], value_loss=s[1], entropy_loss=s[2], clip_fraction=s[3], grad_norm=s[4])
+
+
+class PPO:
+    """The reference's training loop (`model = PPO(...); model.learn(...)`, v2/rl_train.py:38-56) with the rollout resident
+    on the GPU.  `env` is a `GpuWaypointEnv` (auto-reset on); defaults are the reference's hyper-parameters -- with thousands
+    of envs scale `n_steps` down and `batch_size` up."""
+
+    def __init__(self, env, policy=None, learning_rate=2e-4, n_steps=2048, batch_size=128, n_epochs=12, gamma=0.995,
+                 gae_lambda=0.9, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5, normalize_advantage=True,
+                 net_arch=(128, 64, 64), seed=0, obs_normalizer=None, bootstrap_truncated=True, dist=None):
+        if env.state_dtype != torch.float32:
+            raise L.AmenvError("PPO needs the fp32 environment")
+        self.env, self.dist = env, dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.device = env.device
+        self.n_steps, self.batch_size, self.n_epochs = int(n_steps), int(batch_size), int(n_epochs)
+        self.gamma, self.gae_lambda, self.clip_range = float(gamma), float(gae_lambda), float(clip_range)
+        self.ent_coef, self.vf_coef, self.max_grad_norm = float(ent_coef), float(vf_coef), max_grad_norm
+        self.normalize_advantage, self.bootstrap_truncated = bool(normalize_advantage), bool(bootstrap_truncated)
+        self.seed = int(seed)
+        torch.manual_seed(self.seed)   # identical initial weights on every rank (also broadcast below)
+        if policy is None:
+            policy = ActorCritic(env.obs_dim, env.act_dim, net_arch)
+        if policy.obs_dim != env.obs_dim or policy.act_dim != env.act_dim:
+            raise L.AmenvError(f"policy is {policy.obs_dim}->{policy.act_dim}, env is {env.obs_dim}->{env.act_dim}")
+        self.policy = policy.to(self.device).flatten_()
+        if self.world > 1:
+            dist.broadcast(self.policy.flat_param, src=0)
+        self._leaf = self.policy.flat_param.requires_grad_(True)
+        self._leaf.grad = self.policy.flat_grad
+        self.optimizer = torch.optim.Adam([self._leaf], lr=learning_rate, eps=1e-5)
+        self.obs_normalizer = obs_normalizer
+        self.buffer = RolloutBuffer(self.n_steps, env.num_envs, env.obs_dim, env.act_dim, self.device)
+        self._clipped = torch.zeros(env.num_envs, env.act_dim, dtype=torch.float32, device=self.device)
+        self._raw_obs = torch.zeros(env.num_envs, env.obs_dim, dtype=torch.float32, device=self.device) if obs_normalizer else None
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(self.seed * 1000003 + int(getattr(env.cfg, "env_id_offset", 0)))
+        self._draw = 0
+        self._started = False
+        self.num_timesteps = 0
+        self.log = []
+
+    # ---- rollout --------------------------------------------------------------------------------
+    def _first_obs(self):
+        obs = self.env.reset()
+        if self.obs_normalizer is not None:
+            self.obs_normalizer.update(obs)
+            self.obs_normalizer.normalize(obs, out=self.buffer.obs[0])
+        else:
+            self.buffer.obs[0].copy_(obs)
+        self._started = True
+
+    @torch.no_grad()
+    def collect_rollouts(self):
+        """SB3 `OnPolicyAlgorithm.collect_rollouts`: n_steps steps of every env into the buffer, then GAE."""
+        b, env, pol = self.buffer, self.env, self.policy
+        if not self._started:
+            self._first_obs()
+        else:
+            b.obs[0].copy_(b.obs[self.n_steps])
+        gid0 = int(env.cfg.env_id_offset)
+        for t in range(self.n_steps):
+            obs_t = b.obs[t]
+            b.values[t].copy_(pol.critic(obs_t))
+            gaussian_act(pol.actor(obs_t), pol.log_std.data, pol.action_low, pol.action_high, b.actions[t], self._clipped, b.logp[t],
+                         self.seed, self._draw, gid0)
+            self._draw += 1
+            if self.obs_normalizer is None:
+                env.step_into(self._clipped, b.obs[t + 1], b.rewards[t], b.dones[t])
+                term_obs = env.terminal_obs
+            else:   # VecNormalize(norm_obs=True): statistics from the raw observations, the learner sees normalised ones
+                env.step_into(self._clipped, self._raw_obs, b.rewards[t], b.dones[t])
+                self.obs_normalizer.update(self._raw_obs)
+                self.obs_normalizer.normalize(self._raw_obs, out=b.obs[t + 1])
+                term_obs = self.obs_normalizer.normalize(env.terminal_obs) if self.bootstrap_truncated else None
+            if self.bootstrap_truncated:
+                # SB3: reward += gamma * V(terminal_observation) where the episode was cut by the time limit only
+                trunc = ((env.info_bits & (L.INFO_TERMINATED | L.INFO_TRUNCATED)) == L.INFO_TRUNCATED) & (b.dones[t] != 0)
+                b.rewards[t].addcmul_(pol.critic(term_obs), trunc.to(torch.float32), value=self.gamma)
+        b.last_values.copy_(pol.critic(b.obs[self.n_steps]))
+        compute_gae(b, self.gamma, self.gae_lambda)
+        self.num_timesteps += self.n_steps * env.num_envs * self.world
+        return b
+
+    # ---- update ---------------------------------------------------------------------------------
+    def train(self):
+        """SB3 `PPO.train`: n_epochs passes over the buffer in shuffled minibatches."""
+        b, T = self.buffer, self.n_steps
+        n = T * b.n_envs
+        return ppo_update(self.policy, self.optimizer, b.obs[:T].reshape(n, -1), b.actions.reshape(n, -1), b.logp.reshape(n),
+                          b.advantages.reshape(n), b.returns.reshape(n), batch_size=self.batch_size, n_epochs=self.n_epochs,
+                          clip_range=self.clip_range, ent_coef=self.ent_coef, vf_coef=self.vf_coef, max_grad_norm=self.max_grad_norm,
+                          normalize_advantage=self.normalize_advantage, generator=self._gen, dist=self.dist if self.world > 1 else None)
+
+    def learn(self, total_timesteps, log_fn=None):
+        """`model.learn(total_timesteps)` (v2/rl_train.py:56): alternate rollouts and updates until the whole job has taken
+        `total_timesteps` env steps.  Per iteration one record: losses + the Monitor episode statistics of the rollout."""
+        target = self.num_timesteps + int(total_timesteps)
+        while self.num_timesteps < target:
+            self.env.stats(reset=True)
+            self.collect_rollouts()
+            ep = self.env.stats(reset=True)
+            rec = self.train()
+            n_ep = max(int(ep["episodes"]), 1)
+            rec.update(timesteps=self.num_timesteps, episodes=int(ep["episodes"]), ep_rew_mean=ep["return_sum"] / n_ep,
+                       ep_len_mean=ep["length_sum"] / n_ep, success_rate=ep["success"] / n_ep)
+            self.log.append(rec)
+            if log_fn is not None:
+                log_fn(rec)
+        return self
+
+    def predict(self, obs, deterministic=True):
+        if self.obs_normalizer is not None:
+            obs = self.obs_normalizer.normalize(obs)
+        return self.policy.predict(obs, deterministic, self._gen)
+
+    # ---- checkpoints ----------------------------------------------------------------------------
+    def save(self, path):
+        """A zip with SB3's member names: `policy.pth` (SB3 keys: loadable into an SB3 `ActorCriticPolicy`),
+        `policy.optimizer.pth` (this class's Adam state) and `data` (hyper-parameters as plain JSON).  It is NOT a complete
+        SB3 archive (SB3's `data` holds cloudpickled objects); use `policy.pth` to move weights either way."""
+        path = path if str(path).endswith(".zip") else str(path) + ".zip"
+        data = {k: getattr(self, k) for k in ("n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range", "ent_coef",
+                                              "vf_coef", "max_grad_norm", "normalize_advantage", "num_timesteps", "seed")}
+        data.update(learning_rate=self.optimizer.param_groups[0]["lr"], net_arch=list(self.policy.net_arch),
+                    obs_dim=self.policy.obs_dim, act_dim=self.policy.act_dim)
+        with zipfile.ZipFile(path, "w") as z:
+            for name, obj in (("policy.pth", {k: v.detach().cpu().clone() for k, v in self.policy.state_dict().items()}),
+                              ("policy.optimizer.pth", self.optimizer.state_dict())):
+                buf = io.BytesIO()
+                torch.save(obj, buf)
+                z.writestr(name, buf.getvalue())
+            z.writestr("data", json.dumps(data))
+        return path
+
+    def load_policy(self, path_or_state_dict):
+        """Resume from a checkpoint's weights (`PPO.load(CHECKPOINT_PATH, ...)`, v2/rl_train.py:33-35): SB3 zip, this class's
+        zip or a bare `policy.pth`.  Copies into the flat buffer in place."""
+        sd = path_or_state_dict if isinstance(path_or_state_dict, dict) else ActorCritic.read_sb3_state_dict(path_or_state_dict)
+        own = self.policy.state_dict()
+        if set(sd) != set(own):
+            raise L.AmenvError(f"checkpoint keys differ: {sorted(set(sd) ^ set(own))}")
+        with torch.no_grad():
+            for k, v in own.items():
+                if tuple(sd[k].shape) != tuple(v.shape):
+                    raise L.AmenvError(f"{k}: checkpoint shape {tuple(sd[k].shape)} != policy {tuple(v.shape)}")
+                v.copy_(torch.as_tensor(sd[k]).to(v.device))
+        return self

@@ -1,0 +1,179 @@
+"""GPU-resident PPO (BASELINE config 5) on the MI355X: the two HIP kernels of the loop against their
+restatements, the rollout buffer against the environment and the policy, the reference's best checkpoint flying the HIP
+environment, and a short training run."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rl_aerial_manipulator_amd as amd
+from rl_aerial_manipulator_amd import _lib as L
+from rl_aerial_manipulator_amd.ppo import ActorCritic, PPO, RolloutBuffer, compute_gae, gaussian_act
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def fixture_policy(device):
+    z = np.load(os.path.join(GOLD, "policy_2300000.npz"))
+    return ActorCritic.from_sb3({k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("_")}, device=device)
+
+
+@pytest.mark.parametrize("T,N", [(1, 1), (37, 1000), (128, 4096), (5, 70001)])
+def test_gae_kernel_matches_sb3_restatement(T, N):
+    from oracle import oracle as O
+    rng = np.random.RandomState(T * 131 + N)
+    r = rng.randn(T, N).astype(np.float32) * 5
+    v = rng.randn(T, N).astype(np.float32) * 50
+    d = (rng.rand(T, N) < 0.05).astype(np.uint8)
+    lv = rng.randn(N).astype(np.float32) * 50
+    b = RolloutBuffer(T, N, 20, 4, "cuda")
+    b.rewards.copy_(torch.from_numpy(r)); b.values.copy_(torch.from_numpy(v)); b.dones.copy_(torch.from_numpy(d)); b.last_values.copy_(torch.from_numpy(lv))
+    adv, ret = compute_gae(b, 0.995, 0.9)
+    adv_ref, ret_ref = O.gae_reference(r, v, d, lv, 0.995, 0.9)
+    # fp32 accumulation of a sum that can reach ~10 terms of size ~50: 1e-5 relative to the running magnitude
+    scale = np.maximum(1.0, np.abs(adv_ref))
+    assert (np.abs(adv.cpu().numpy() - adv_ref) / scale).max() < 2e-5
+    assert (np.abs(ret.cpu().numpy() - ret_ref) / np.maximum(1.0, np.abs(ret_ref))).max() < 2e-5
+    # where an episode ended, nothing from later steps leaks in: A_t = r_t - V_t exactly
+    m = torch.from_numpy(d != 0).cuda()
+    assert torch.equal(adv[m], (b.rewards - b.values)[m])
+
+
+@pytest.mark.parametrize("A", [4, 7])
+def test_gaussian_act_kernel(A):
+    n = 200000
+    dev = "cuda"
+    mean = torch.randn(n, A, device=dev)
+    log_std = torch.linspace(-1.0, 0.3, A, device=dev)
+    low = torch.tensor([0.0] + [-1.0] * (A - 1), device=dev)
+    high = torch.tensor([2.0] + [1.0] * (A - 1), device=dev)
+    raw, clipped, logp = torch.zeros(n, A, device=dev), torch.zeros(n, A, device=dev), torch.zeros(n, device=dev)
+    gaussian_act(mean, log_std, low, high, raw, clipped, logp, seed=7, draw=3)
+    z = ((raw - mean) * torch.exp(-log_std)).double()
+    # standard normal noise: moments per action dimension, independence across dimensions, tails
+    assert float(z.mean(0).abs().max()) < 0.01 and float((z.var(0) - 1).abs().max()) < 0.02
+    assert float(((z ** 4).mean(0) - 3).abs().max()) < 0.1
+    c = torch.corrcoef(z.T) - torch.eye(A, device=dev, dtype=torch.float64)
+    assert float(c.abs().max()) < 0.01
+    assert 4.0 < float(z.abs().max()) < 6.5
+    # log-prob is the diagonal-Gaussian density of the raw action; clip is the action-space clip
+    ref = torch.distributions.Normal(mean, log_std.exp()).log_prob(raw).sum(-1)
+    assert float((logp - ref).abs().max()) < 2e-4        # (a-mu)/sigma re-derived from a rounded a: ~1e-5 relative on z
+    assert torch.equal(clipped, torch.minimum(torch.maximum(raw, low), high))
+    # another draw index -> new noise; same (seed, global env id, draw) -> same noise however the envs are sharded
+    raw2, c2, l2 = torch.zeros_like(raw), torch.zeros_like(raw), torch.zeros_like(logp)
+    gaussian_act(mean, log_std, low, high, raw2, c2, l2, seed=7, draw=4)
+    assert float((raw2 - raw).abs().mean()) > 0.1
+    h = n // 2
+    ra, ca, la = torch.zeros(h, A, device=dev), torch.zeros(h, A, device=dev), torch.zeros(h, device=dev)
+    gaussian_act(mean[h:].contiguous(), log_std, low, high, ra, ca, la, seed=7, draw=3, env_id_offset=h)
+    assert torch.equal(ra, raw[h:]) and torch.equal(la, logp[h:])
+
+
+def test_reference_policy_flies_the_gpu_env():
+    """The checkpoint the reference's README names as best (v2/README.md:55) in closed loop on the HIP environment: >95 %
+    of episodes end in success, with the return and length the CPU oracle gives for the same policy (tests/test_ppo_cpu.py)."""
+    env = amd.GpuWaypointEnv(2048, seed=3)
+    pol = fixture_policy(env.device)
+    obs = env.reset()
+    env.stats(reset=True)
+    for _ in range(1700):
+        obs, _, _, _ = env.step(pol.predict(obs))
+    s = env.stats()
+    assert s["episodes"] > 3000
+    assert s["success"] / s["episodes"] > 0.95
+    assert 12000 < s["return_sum"] / s["episodes"] < 26000
+    assert 500 < s["length_sum"] / s["episodes"] < 900
+
+
+def test_rollout_buffer_is_consistent_with_policy_and_env():
+    from oracle import oracle as O
+    env = amd.GpuWaypointEnv(512, seed=11, max_episode_steps=40)           # short time limit: truncations inside the rollout
+    algo = PPO(env, policy=fixture_policy(env.device), n_steps=96, batch_size=4096, n_epochs=1, seed=5)
+    with torch.no_grad():
+        algo.policy.log_std.data.fill_(-1.5)
+    b = algo.collect_rollouts()
+    T = algo.n_steps
+    n = T * env.num_envs
+    with torch.no_grad():
+        values, logp, _ = algo.policy.evaluate_actions(b.obs[:T].reshape(n, -1), b.actions.reshape(n, -1))
+    assert float((logp - b.logp.reshape(n)).abs().max()) < 2e-4             # ratio == 1 at the first minibatch, as in SB3
+    assert float((values - b.values.reshape(n)).abs().max()) < 1e-3 * max(1.0, float(values.abs().max()))
+    d = b.dones.bool()
+    assert 0 < int(d.sum()) < n // 4
+    # the time limit fires at step 41 of an episode: rewards there carry gamma * V(terminal_observation)
+    assert int(d[40].sum()) > 400
+    adv_ref, ret_ref = O.gae_reference(b.rewards.cpu().numpy(), b.values.cpu().numpy(), b.dones.cpu().numpy(), b.last_values.cpu().numpy(), 0.995, 0.9)
+    assert (np.abs(b.advantages.cpu().numpy() - adv_ref) / np.maximum(1.0, np.abs(adv_ref))).max() < 2e-5
+    # second rollout continues from the last observation of the first
+    last = b.obs[T].clone()
+    b2 = algo.collect_rollouts()
+    assert torch.equal(b2.obs[0], last)
+    assert algo.num_timesteps == 2 * n
+
+
+def test_truncation_bootstrap_matches_sb3_rule():
+    """reward += gamma * V(terminal_observation) only where the episode was cut by the time limit (SB3 collect_rollouts)."""
+    def rollout(bootstrap):
+        env = amd.GpuWaypointEnv(256, seed=2, max_episode_steps=10)
+        algo = PPO(env, policy=fixture_policy(env.device), n_steps=11, seed=1, bootstrap_truncated=bootstrap)
+        return env, algo, algo.collect_rollouts()
+    _, _, b0 = rollout(False)
+    env, algo, b1 = rollout(True)
+    assert torch.equal(b0.actions, b1.actions) and torch.equal(b0.dones, b1.dones)
+    diff = b1.rewards - b0.rewards
+    trunc = ((env.info_bits & 3) == L.INFO_TRUNCATED) & b1.dones[10].bool()     # the 11th step is past the 10-step limit
+    assert int(trunc.sum()) > 200
+    assert float(diff[:10].abs().max()) == 0.0 and float(diff[10][~trunc].abs().max() if bool((~trunc).any()) else 0.0) == 0.0
+    with torch.no_grad():
+        v = algo.policy.critic(env.terminal_obs)[trunc]                          # still in the env's buffer after the last step
+    assert torch.allclose(diff[10][trunc], 0.995 * v, rtol=1e-4, atol=1e-3)
+    assert float(v.abs().min()) > 0.0
+
+
+def test_learn_runs():
+    env = amd.GpuWaypointEnv(1024, seed=0)
+    algo = PPO(env, n_steps=64, batch_size=8192, n_epochs=4, seed=0)
+    p0 = algo.policy.flat_param.detach().clone()
+    algo.learn(3 * 64 * 1024)
+    assert len(algo.log) == 3 and algo.num_timesteps == 3 * 64 * 1024
+    assert all(math.isfinite(v) for rec in algo.log for v in rec.values())
+    assert float((algo.policy.flat_param.detach() - p0).abs().max()) > 1e-4
+    assert all(rec["grad_norm"] > 0 and rec["episodes"] > 0 for rec in algo.log)
+    assert algo.log[0]["clip_fraction"] < 0.5
+
+
+def test_fine_tuning_the_reference_checkpoint_keeps_it_flying(tmp_path):
+    """`PPO.load(CHECKPOINT_PATH, env=env, ...)` + `learn` (v2/rl_train.py:33-35,56): resume from the reference's weights,
+    train briefly with the reference's hyper-parameters (scaled batch), save, reload -- the policy still succeeds."""
+    env = amd.GpuWaypointEnv(2048, seed=21)
+    algo = PPO(env, n_steps=128, batch_size=16384, n_epochs=2, ent_coef=1e-4, seed=3)
+    z = np.load(os.path.join(GOLD, "policy_2300000.npz"))
+    algo.load_policy({k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("_")})
+    algo.learn(2 * 128 * 2048)
+    path = algo.save(os.path.join(tmp_path, "ppo_model_gpu"))
+    pol = ActorCritic.from_sb3(path, device=env.device)
+    assert torch.equal(pol.flatten_().flat_param, algo.policy.flat_param.detach())
+    ev = amd.GpuWaypointEnv(1024, seed=99)
+    obs = ev.reset()
+    ev.stats(reset=True)
+    for _ in range(1700):
+        obs, _, _, _ = ev.step(pol.predict(obs))
+    s = ev.stats()
+    assert s["episodes"] > 1500 and s["success"] / s["episodes"] > 0.9
+
+
+def test_ppo_with_arm_env_and_obs_normalizer():
+    env = amd.GpuWaypointEnv(512, vehicle="hexa_arm", seed=4)
+    norm = amd.ObsNormalizer(env.obs_dim, device=env.device_index)
+    algo = PPO(env, n_steps=32, batch_size=4096, n_epochs=2, seed=0, obs_normalizer=norm)
+    algo.learn(2 * 32 * 512)
+    assert algo.policy.num_parameters() == 2 * (26 * 128 + 128 + 128 * 64 + 64 + 64 * 64 + 64) + 64 * 7 + 7 + 64 + 1 + 7
+    assert all(math.isfinite(v) for rec in algo.log for v in rec.values())
+    mean, var, count = norm.get()
+    assert abs(count - (2 * 32 + 1) * 512) < 1.0
+    assert float(algo.buffer.obs.abs().max()) <= 10.0                         # clip_obs
