@@ -12,7 +12,8 @@ from . import vec_env
 from .gpu_env import GpuWaypointEnv
 from .vec_env import GpuVecEnv
 from .obs_norm import GpuVecNormalize, ObsNormalizer
-from . import ppo
+from . import baselines, ppo
+from .baselines import MinSnapTrajectory, PidController, PidWaypointPolicy
 from .ppo import PPO, ActorCritic
 
-__all__ = ["GpuWaypointEnv", "GpuVecEnv", "GpuVecNormalize", "ObsNormalizer", "PPO", "ActorCritic", "ppo", "vec_env", "AmenvError", "_lib", "sharding"]
+__all__ = ["GpuWaypointEnv", "GpuVecEnv", "GpuVecNormalize", "ObsNormalizer", "PPO", "ActorCritic", "ppo", "baselines", "PidController", "MinSnapTrajectory", "PidWaypointPolicy", "vec_env", "AmenvError", "_lib", "sharding"]

@@ -27,10 +27,48 @@ from torch import nn
 from . import _lib as L
 
 
+_SPLIT = 256   # rows per partial product of the weight gradient
+
+
+class _TallSkinnyLinearFn(torch.autograd.Function):
+    """y = x W^T + b with a weight gradient shaped for this workload.  dW = dY^T X is a [out, in] <= 128 x 128 result
+    reduced over the whole minibatch (65,536 rows): the library GEMM picked for that shape runs in one or two workgroups
+    without split-K (rocprof, profiles/r01/ppo_update_kernel_stats_before.csv: ~200 us per call, 55 % of the update).
+    Here the batch is cut into 256-row slabs, one strided-batched GEMM forms the per-slab products on all CUs and a sum
+    over slabs finishes the reduction."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        rows = x.shape[0]
+        c = rows // _SPLIT
+        m = c * _SPLIT
+        gw = torch.bmm(gy[:m].view(c, _SPLIT, -1).transpose(1, 2), x[:m].view(c, _SPLIT, -1)).sum(0)
+        if m < rows:
+            gw = gw + gy[m:].t() @ x[m:]
+        return gx, gw, gy.sum(0)
+
+
+class _Linear(nn.Linear):
+    """nn.Linear (same parameters and state-dict keys) that switches to the tall-skinny weight gradient for big batches."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.shape[0] >= 2 * _SPLIT and torch.is_grad_enabled() and x.is_contiguous():
+            return _TallSkinnyLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def _mlp(sizes):
     layers = []
     for a, b in zip(sizes[:-1], sizes[1:]):
-        layers += [nn.Linear(a, b), nn.Tanh()]
+        layers += [_Linear(a, b), nn.Tanh()]
     return nn.Sequential(*layers)
 
 
@@ -53,8 +91,8 @@ class ActorCritic(nn.Module):
         self.obs_dim, self.act_dim, self.net_arch = int(obs_dim), int(act_dim), tuple(net_arch)
         self.log_std = nn.Parameter(torch.full((self.act_dim,), float(log_std_init)))
         self.mlp_extractor = _MlpExtractor(self.obs_dim, self.net_arch)
-        self.action_net = nn.Linear(self.net_arch[-1], self.act_dim)
-        self.value_net = nn.Linear(self.net_arch[-1], 1)
+        self.action_net = _Linear(self.net_arch[-1], self.act_dim)
+        self.value_net = _Linear(self.net_arch[-1], 1)
         # action space of WaypointQuadEnv (v2/rl_env_scaledObs.py:20-24); joint commands of the arm are in [-1, 1] too
         lo = [0.0] + [-1.0] * (self.act_dim - 1) if action_low is None else action_low
         hi = [2.0] + [1.0] * (self.act_dim - 1) if action_high is None else action_high
@@ -203,19 +241,19 @@ def ppo_update(policy, optimizer, obs, actions, old_logp, advantages, returns, *
     stats = torch.zeros(5, device=obs.device)
     n_batches = 0
     for epoch in range(n_epochs):
+        # one shuffle of the whole buffer per epoch (5 gathers), then every minibatch is a contiguous slice
         perm = torch.randperm(n, device=obs.device, generator=generator)
-        if epoch == n_epochs - 1:
-            stats.zero_()
-            n_batches = 0
+        obs_s, act_s, olp_s, adv_s, ret_s = obs[perm], actions[perm], old_logp[perm], advantages[perm], returns[perm]
+        last = epoch == n_epochs - 1
         for start in range(0, n, batch_size):
-            idx = perm[start:start + batch_size]
-            adv = advantages[idx]
+            sl = slice(start, min(start + batch_size, n))
+            adv = adv_s[sl]
             if normalize_advantage and adv.numel() > 1:
                 adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-            values, logp, entropy = policy.evaluate_actions(obs[idx], actions[idx])
-            ratio = torch.exp(logp - old_logp[idx])
+            values, logp, entropy = policy.evaluate_actions(obs_s[sl], act_s[sl])
+            ratio = torch.exp(logp - olp_s[sl])
             pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1.0 - clip_range, 1.0 + clip_range)).mean()
-            vl = torch.nn.functional.mse_loss(returns[idx], values)
+            vl = torch.nn.functional.mse_loss(ret_s[sl], values)
             el = -entropy.mean()
             loss = pl + ent_coef * el + vf_coef * vl
             policy.flat_grad.zero_()
@@ -223,13 +261,15 @@ def ppo_update(policy, optimizer, obs, actions, old_logp, advantages, returns, *
             if world > 1:
                 dist.all_reduce(policy.flat_grad)
                 policy.flat_grad.div_(world)
-            gn = policy.flat_grad.norm(2)
+            if max_grad_norm is not None or last:
+                gn = policy.flat_grad.norm(2)
             if max_grad_norm is not None:
                 policy.flat_grad.mul_(torch.clamp(max_grad_norm / (gn + 1e-6), max=1.0))
             optimizer.step()
-            with torch.no_grad():
-                stats += torch.stack([pl.detach(), vl.detach(), el.detach(), ((ratio.detach() - 1.0).abs() > clip_range).float().mean(), gn])
-            n_batches += 1
+            if last:   # losses are reported for the last epoch only (no host sync inside the loop)
+                with torch.no_grad():
+                    stats += torch.stack([pl.detach(), vl.detach(), el.detach(), ((ratio.detach() - 1.0).abs() > clip_range).float().mean(), gn])
+                n_batches += 1
     s = (stats / max(n_batches, 1)).tolist()
     return dict(policy_loss=s[0], value_loss=s[1], entropy_loss=s[2], clip_fraction=s[3], grad_norm=s[4])
 

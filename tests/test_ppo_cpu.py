@@ -231,3 +231,23 @@ def test_reference_policy_flies_the_oracle_env():
     assert eps >= 100 and succ / eps > 0.95
     assert 12000 < np.mean(rets) < 26000                # README reports episode returns of this order for the checkpoint
     assert 500 < np.mean(lens) < 900                    # reach at 150-300 steps + 500-step hold
+
+
+def test_tall_skinny_linear_gradients_match_nn_linear():
+    """The slab-wise weight gradient (ragged last slab included) against torch's own Linear backward."""
+    from rl_aerial_manipulator_amd.ppo import _Linear
+    torch.manual_seed(3)
+    lin = _Linear(20, 128).double()
+    x = torch.randn(1000, 20, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(1000, 128, dtype=torch.float64)
+    y = lin(x)
+    assert y.grad_fn is not None and "TallSkinny" in type(y.grad_fn).__name__
+    y.backward(gy)
+    x2 = x.detach().clone().requires_grad_(True)
+    w = lin.weight.detach().clone().requires_grad_(True)
+    b = lin.bias.detach().clone().requires_grad_(True)
+    torch.nn.functional.linear(x2, w, b).backward(gy)
+    assert torch.allclose(y, torch.nn.functional.linear(x.detach(), w.detach(), b.detach()), rtol=1e-12, atol=1e-12)
+    assert torch.allclose(lin.weight.grad, w.grad, rtol=1e-11, atol=1e-11)
+    assert torch.allclose(lin.bias.grad, b.grad, rtol=1e-11, atol=1e-11)
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-11, atol=1e-11)

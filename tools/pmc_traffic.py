@@ -44,7 +44,8 @@ def main():
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)   # rocprofv3 runs with cwd=/tmp
     os.makedirs(a.out, exist_ok=True)
-    res = {}
+    path = os.path.join(a.out, "traffic.json")
+    res = json.load(open(path)) if os.path.exists(path) else {}    # merge: one invocation per vehicle
     for n in a.envs:
         f_kib, f_cal = collect("FETCH_SIZE", n, a.vehicle, a.out)
         w_kib, w_cal = collect("WRITE_SIZE", n, a.vehicle, a.out)
@@ -55,7 +56,7 @@ def main():
                                           calibration_copy_256MiB=dict(fetch_kib_raw=f_cal, write_kib_raw=w_cal))
         print(f"N={n:8d}: FETCH_SIZE {f_kib:10.1f} KiB (x2 -> {fetch/1e6:8.3f} MB)  WRITE_SIZE {w_kib:10.1f} KiB ({write/1e6:8.3f} MB)  "
               f"per env-step {(fetch + write) / n:7.1f} B   calibration copy(256 MiB): fetch {f_cal} KiB write {w_cal} KiB", flush=True)
-    with open(os.path.join(a.out, "traffic.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(res, f, indent=1)
 
 
