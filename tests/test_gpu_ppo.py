@@ -189,3 +189,19 @@ def test_ppo_with_arm_env_and_obs_normalizer():
     mean, var, count = norm.get()
     assert abs(count - (2 * 32 + 1) * 512) < 1.0
     assert float(algo.buffer.obs.abs().max()) <= 10.0                         # clip_obs
+
+
+def test_graph_captured_update_equals_eager_update():
+    """The HIP-graph replay of the minibatch step is the same arithmetic as the eager step: same rollout, same shuffles ->
+    the same parameters (up to GEMM kernel selection) after 2 epochs x 8 minibatches, on one GPU."""
+    out = []
+    for use_graph in (False, True):
+        env = amd.GpuWaypointEnv(1024, seed=8)
+        algo = PPO(env, policy=fixture_policy(env.device), n_steps=64, batch_size=8192, n_epochs=2, seed=4, use_graph=use_graph)
+        algo.collect_rollouts()
+        rec = algo.train()
+        out.append((algo.policy.flat_param.detach().clone(), rec, algo._step._graphs is not None))
+    (p0, r0, g0), (p1, r1, g1) = out
+    assert not g0 and g1                                                     # the second run really replayed graphs
+    assert float((p0 - p1).abs().max()) < 1e-5
+    assert abs(r0["value_loss"] - r1["value_loss"]) <= 1e-4 * abs(r0["value_loss"]) and abs(r0["grad_norm"] - r1["grad_norm"]) <= 1e-3 * r0["grad_norm"]
