@@ -238,11 +238,13 @@ class MinibatchStep:
     all-reduce of the flat gradient buffer.  A ragged last minibatch (n % batch_size) always runs eagerly."""
 
     def __init__(self, policy, optimizer, *, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5,
-                 normalize_advantage=True, dist=None, use_graph=None):
+                 normalize_advantage=True, dist=None, use_graph=None, split_graphs=None):
         if policy.flat_grad is None:
             policy.flatten_()
         self.policy, self.optimizer, self.dist = policy, optimizer, dist
         self.world = dist.get_world_size() if dist is not None else 1
+        # two graphs around an eager all-reduce whenever there is a process group to talk to (tests force it with 1 rank)
+        self.split = (self.world > 1) if split_graphs is None else bool(split_graphs)
         self.clip_range, self.ent_coef, self.vf_coef = float(clip_range), float(ent_coef), float(vf_coef)
         self.max_grad_norm, self.normalize_advantage = max_grad_norm, bool(normalize_advantage)
         dev = policy.flat_param.device
@@ -270,9 +272,10 @@ class MinibatchStep:
             self.stats[3] = ((ratio.detach() - 1.0).abs() > c).float().mean()
 
     def _exchange(self):
-        if self.world > 1:
+        if self.dist is not None and (self.world > 1 or self.split):
             self.dist.all_reduce(self.policy.flat_grad)
-            self.policy.flat_grad.div_(self.world)
+            if self.world > 1:
+                self.policy.flat_grad.div_(self.world)
 
     def _apply(self):
         g = self.policy.flat_grad
@@ -294,7 +297,7 @@ class MinibatchStep:
             s.copy_(t)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
-        if self.world == 1:
+        if not self.split:
             with torch.cuda.graph(g1):
                 self._forward_backward(*self._static)
                 self._apply()

@@ -205,3 +205,33 @@ def test_graph_captured_update_equals_eager_update():
     assert not g0 and g1                                                     # the second run really replayed graphs
     assert float((p0 - p1).abs().max()) < 1e-5
     assert abs(r0["value_loss"] - r1["value_loss"]) <= 1e-4 * abs(r0["value_loss"]) and abs(r0["grad_norm"] - r1["grad_norm"]) <= 1e-3 * r0["grad_norm"]
+
+
+def test_split_graph_update_with_rccl_all_reduce_between():
+    """The multi-GPU shape of the update on one GPU: a 1-rank RCCL (nccl backend) process group, forward/backward graph ->
+    eager all-reduce of the flat gradient buffer -> clip + Adam graph.  With one rank the all-reduce is the identity, so the
+    result must equal the single-graph update."""
+    import socket
+    import torch.distributed as dist
+    from rl_aerial_manipulator_amd.ppo import MinibatchStep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        out = []
+        for split in (False, True):
+            env = amd.GpuWaypointEnv(1024, seed=8)
+            algo = PPO(env, policy=fixture_policy(env.device), n_steps=64, batch_size=8192, n_epochs=2, seed=4)
+            algo._step = MinibatchStep(algo.policy, algo.optimizer, ent_coef=algo.ent_coef, dist=dist, use_graph=True, split_graphs=split)
+            algo.collect_rollouts()
+            algo.train()
+            out.append((algo.policy.flat_param.detach().clone(), algo._step._graphs))
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        dist.barrier()
+        assert out[0][1][1] is None and out[1][1][1] is not None          # one graph vs two
+        assert float((out[0][0] - out[1][0]).abs().max()) < 1e-6 and float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
