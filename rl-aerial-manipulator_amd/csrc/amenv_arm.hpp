@@ -118,7 +118,8 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   M3<T> R{{T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}};
   V3<T> p{T(0), T(0), T(0)}, pd = p, pdd = p, w = p, al = p;
   // (compile-time recursion over the joints so each joint's axis code is a constant)
-  auto joint = [&](auto kc) {
+  // advance: carry the chain (R, p, pd, pdd, w, al) across joint k.  leaf: link k's CoM motion, inertia and its sums.
+  auto advance = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     constexpr int ac = AX::code[k];
     const V3<T> o{A.jo[k][0], A.jo[k][1], A.jo[k][2]}, ax{A.ja[k][0], A.ja[k][1], A.ja[k][2]};
@@ -134,10 +135,25 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
     w = w + y[16 + k] * z;
     if constexpr (ac >= 0) rotate_about_column<ac>(R, y[13 + k]);
     else R = mul(R, rodrigues(ax, y[13 + k]));
+  };
+  // sums of one link given its CoM position / velocity / acceleration (relative to the body frame) and J (body axes)
+  auto accumulate = [&](T m, V3<T> r, V3<T> b, const M3<T>& J, V3<T> aa, V3<T> Om) {
+    const V3<T> Jaa = mul(J, aa), JOm = mul(J, Om);
+    S = S + m * r; fb = fb + m * b;
+    nb = nb + m * cross(r, b) + Jaa + cross(Om, JOm);
+    const T r2 = dot(r, r);                                            // I_O += J + m (|r|^2 1 - r r^T)
+    IO[0] += J.m[0] + m * (r2 - r.x * r.x);
+    IO[1] += J.m[1] - m * (r.x * r.y);
+    IO[2] += J.m[2] - m * (r.x * r.z);
+    IO[3] += J.m[4] + m * (r2 - r.y * r.y);
+    IO[4] += J.m[5] - m * (r.y * r.z);
+    IO[5] += J.m[8] + m * (r2 - r.z * r.z);
+  };
+  auto leaf = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     const V3<T> Rc = mul(R, V3<T>{A.lc[k][0], A.lc[k][1], A.lc[k][2]});
     const V3<T> wRc = cross(w, Rc);
     const V3<T> r = p + Rc, u = pd + wRc, a_ = pdd + cross(al, Rc) + cross(w, wRc);
-    const T m = A.lm[k];
     const V3<T> b = cross(om, cross(om, r)) + T(2) * cross(om, u) + a_;
     // link inertia in body axes, once: J = R I R^T (symmetric, 6 entries); every rotational term and I_O use it
     const M3<T> Ik{{A.li[k][0], A.li[k][1], A.li[k][2], A.li[k][1], A.li[k][3], A.li[k][4], A.li[k][2], A.li[k][4], A.li[k][5]}};
@@ -145,21 +161,53 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
     const T Jxx = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[0], R.m[1], R.m[2]), Jxy = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[3], R.m[4], R.m[5]);
     const T Jxz = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[6], R.m[7], R.m[8]), Jyy = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[3], R.m[4], R.m[5]);
     const T Jyz = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[6], R.m[7], R.m[8]), Jzz = dot3_(RI.m[6], RI.m[7], RI.m[8], R.m[6], R.m[7], R.m[8]);
-    const M3<T> J{{Jxx, Jxy, Jxz, Jxy, Jyy, Jyz, Jxz, Jyz, Jzz}};
-    const V3<T> aa = al + cross(om, w), Om = om + w;
-    const V3<T> Jaa = mul(J, aa), JOm = mul(J, Om);
-    S = S + m * r; fb = fb + m * b;
-    nb = nb + m * cross(r, b) + Jaa + cross(Om, JOm);
-    // I_O += J + m (|r|^2 1 - r r^T)
-    const T r2 = dot(r, r);
-    IO[0] += Jxx + m * (r2 - r.x * r.x);
-    IO[1] += Jxy - m * (r.x * r.y);
-    IO[2] += Jxz - m * (r.x * r.z);
-    IO[3] += Jyy + m * (r2 - r.y * r.y);
-    IO[4] += Jyz - m * (r.y * r.z);
-    IO[5] += Jzz + m * (r2 - r.z * r.z);
+    accumulate(A.lm[k], r, b, M3<T>{{Jxx, Jxy, Jxz, Jxy, Jyy, Jyz, Jxz, Jyz, Jzz}}, al + cross(om, w), om + w);
   };
-  joint(std::integral_constant<int, 0>{}); joint(std::integral_constant<int, 1>{}); joint(std::integral_constant<int, 2>{});
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+  if constexpr (AX::code[0] == 2 && AX::code[1] == 0) {
+    // The repo's arm: joint 1 about z at the start of the chain (R = 1, p = pd = pdd = w = al = 0), joint 2 about x.  Written
+    // out with the zeros / ones of Rz(th1), w = (0,0,wz), al = (0,0,az) removed: ~180 of the ~960 operations of one RHS.
+    T s0, c0;
+    sincos_(y[13], s0, c0);
+    const T wz = y[16], az = thdd[0];
+    const V3<T> o0{A.jo[0][0], A.jo[0][1], A.jo[0][2]};
+    {  // link 1
+      const T lx = A.lc[0][0], ly = A.lc[0][1], lz = A.lc[0][2];
+      const V3<T> Rc{fma_(c0, lx, -(s0 * ly)), fma_(s0, lx, c0 * ly), lz};
+      const V3<T> u{-(wz * Rc.y), wz * Rc.x, T(0)};                                   // w x Rc
+      const V3<T> r = o0 + Rc;
+      const T ax_ = fma_(-az, Rc.y, -(wz * u.y)), ay_ = fma_(az, Rc.x, wz * u.x);      // al x Rc + w x (w x Rc); z part 0
+      const V3<T> oor = cross(om, cross(om, r));
+      const V3<T> b{fma_(T(-2) * om.z, u.y, oor.x) + ax_, fma_(T(2) * om.z, u.x, oor.y) + ay_,
+                    fma_(T(2), fma_(om.x, u.y, -(om.y * u.x)), oor.z)};
+      // J = Rz I Rz^T
+      const T Ixx = A.li[0][0], Ixy = A.li[0][1], Ixz = A.li[0][2], Iyy = A.li[0][3], Iyz = A.li[0][4], Izz = A.li[0][5];
+      const T q00 = fma_(c0, Ixx, -(s0 * Ixy)), q01 = fma_(c0, Ixy, -(s0 * Iyy)), q02 = fma_(c0, Ixz, -(s0 * Iyz));
+      const T q10 = fma_(s0, Ixx, c0 * Ixy), q11 = fma_(s0, Ixy, c0 * Iyy), q12 = fma_(s0, Ixz, c0 * Iyz);
+      const T Jxx = fma_(q00, c0, -(q01 * s0)), Jxy = fma_(q00, s0, q01 * c0), Jyy = fma_(q10, s0, q11 * c0);
+      accumulate(A.lm[0], r, b, M3<T>{{Jxx, Jxy, q02, Jxy, Jyy, q12, q02, q12, Izz}},
+                 V3<T>{om.y * wz, -(om.x * wz), az}, V3<T>{om.x, om.y, om.z + wz});
+    }
+    {  // across joint 2 (axis x of the frame Rz(th1)): chain quantities at joint 2, then R = Rz(th1) Rx(th2)
+      const T ox = A.jo[1][0], oy = A.jo[1][1], oz = A.jo[1][2];
+      const V3<T> Ro{fma_(c0, ox, -(s0 * oy)), fma_(s0, ox, c0 * oy), oz};
+      pd = V3<T>{-(wz * Ro.y), wz * Ro.x, T(0)};                                        // w x Ro
+      pdd = V3<T>{fma_(-az, Ro.y, -(wz * pd.y)), fma_(az, Ro.x, wz * pd.x), T(0)};
+      p = o0 + Ro;
+      const T td = y[17], tdd = thdd[1];
+      al = V3<T>{fma_(tdd, c0, -(td * (wz * s0))), fma_(tdd, s0, td * (wz * c0)), az};   // + thdd z + thd (w x z), z = (c0, s0, 0)
+      w = V3<T>{td * c0, td * s0, wz};
+      T s1, c1;
+      sincos_(y[14], s1, c1);
+      R = M3<T>{{c0, -(c1 * s0), s1 * s0, s0, c1 * c0, -(s1 * c0), T(0), s1, c1}};
+    }
+    leaf(K1{});
+    advance(K2{}); leaf(K2{});
+  } else {
+    advance(K0{}); leaf(K0{});
+    advance(K1{}); leaf(K1{});
+    advance(K2{}); leaf(K2{});
+  }
   // external wrench about O: rotor thrust / moments, gravity at every CoM
   V3<T> f = A.mtot * gb - fb;
   f.z += F;
