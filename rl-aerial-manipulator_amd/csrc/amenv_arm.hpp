@@ -92,9 +92,31 @@ __device__ __forceinline__ void rotate_about_column(M3<T>& R, T th) {
   }
 }
 
+// Two-wave variant (small batches; step_kernel_arm2w): the 64 environments of a tile are integrated by TWO wavefronts of one
+// workgroup.  Both carry the full 19-state RK4; per RHS the helper wave computes link 3 (chain across joint 3 + its Newton-Euler
+// terms), the main wave the base, links 1-2, the 3x3 solve.  They meet twice per RHS through LDS: helper -> main 21 partial sums,
+// main -> helper the 6 solved accelerations.  The partials are added in the order the one-wave code adds them, so both variants
+// (and the rollout kernel) give bit-identical trajectories.
+enum { ARM_ROLE_ALL = 0, ARM_ROLE_MAIN = 1, ARM_ROLE_HELPER = 2 };
+constexpr int kArmXchgSlots = 27;   // 21 partial sums + wd(3) + vd(3), [slot][64 lanes] floats
+struct NoXchg {};
+struct LdsXchg {
+  float* base; int lane;
+  __device__ __forceinline__ void put(int slot, float v) const { base[slot * 64 + lane] = v; }
+  __device__ __forceinline__ float get(int slot) const { return base[slot * 64 + lane]; }
+  // barrier fenced for the instruction scheduler on both sides: ALU work must neither sink below nor rise above it, or the two
+  // waves stop overlapping (observed: the main wave's share of RHS n+1 was scheduled in front of the barrier that releases the helper)
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+
 // 19 derivatives of the arm vehicle.  y: state, F / M: rotor wrench after the mixer, cmd: joint position commands.
-template <typename T, typename AX, typename PT>
-__device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
+template <typename T, typename AX, typename PT, int ROLE = ARM_ROLE_ALL, typename X = NoXchg>
+__device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{}) {
+  static_assert(ROLE == ARM_ROLE_ALL || (AX::code[0] == 2 && AX::code[1] == 0 && sizeof(T) == 4), "two-wave roles: z,x,x arm, fp32");
   const V3<T> om{y[10], y[11], y[12]};
   // rotation of the normalised quaternion (body -> world is its transpose, as in the rigid model)
   const T n2 = fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9])));
@@ -139,6 +161,16 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   // sums of one link given its CoM position / velocity / acceleration (relative to the body frame) and J (body axes)
   auto accumulate = [&](T m, V3<T> r, V3<T> b, const M3<T>& J, V3<T> aa, V3<T> Om) {
     const V3<T> Jaa = mul(J, aa), JOm = mul(J, Om);
+    if constexpr (ROLE == ARM_ROLE_HELPER) {   // hand every addend to the main wave separately (same association there)
+      const V3<T> mr = m * r, mb = m * b, mrb = m * cross(r, b), gy = cross(Om, JOm);
+      const T r2 = dot(r, r);
+      const T v[21] = {mr.x, mr.y, mr.z, mb.x, mb.y, mb.z, mrb.x, mrb.y, mrb.z, Jaa.x, Jaa.y, Jaa.z, gy.x, gy.y, gy.z,
+                       J.m[0] + m * (r2 - r.x * r.x), J.m[1] - m * (r.x * r.y), J.m[2] - m * (r.x * r.z),
+                       J.m[4] + m * (r2 - r.y * r.y), J.m[5] - m * (r.y * r.z), J.m[8] + m * (r2 - r.z * r.z)};
+#pragma unroll
+      for (int q = 0; q < 21; q++) x.put(q, float(v[q]));
+      return;
+    }
     S = S + m * r; fb = fb + m * b;
     nb = nb + m * cross(r, b) + Jaa + cross(Om, JOm);
     const T r2 = dot(r, r);                                            // I_O += J + m (|r|^2 1 - r r^T)
@@ -171,7 +203,7 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
     sincos_(y[13], s0, c0);
     const T wz = y[16], az = thdd[0];
     const V3<T> o0{A.jo[0][0], A.jo[0][1], A.jo[0][2]};
-    {  // link 1
+    if constexpr (ROLE != ARM_ROLE_HELPER) {  // link 1
       const T lx = A.lc[0][0], ly = A.lc[0][1], lz = A.lc[0][2];
       const V3<T> Rc{fma_(c0, lx, -(s0 * ly)), fma_(s0, lx, c0 * ly), lz};
       const V3<T> u{-(wz * Rc.y), wz * Rc.x, T(0)};                                   // w x Rc
@@ -201,29 +233,57 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
       sincos_(y[14], s1, c1);
       R = M3<T>{{c0, -(c1 * s0), s1 * s0, s0, c1 * c0, -(s1 * c0), T(0), s1, c1}};
     }
-    leaf(K1{});
-    advance(K2{}); leaf(K2{});
+    if constexpr (ROLE != ARM_ROLE_HELPER) leaf(K1{});
+    if constexpr (ROLE != ARM_ROLE_MAIN) { advance(K2{}); leaf(K2{}); }
   } else {
     advance(K0{}); leaf(K0{});
     advance(K1{}); leaf(K1{});
     advance(K2{}); leaf(K2{});
   }
-  // external wrench about O: rotor thrust / moments, gravity at every CoM
-  V3<T> f = A.mtot * gb - fb;
-  f.z += F;
-  const V3<T> n = M + cross(S, gb) - nb;
-  // I_c = I_O - (|S|^2 1 - S S^T)/mtot ; solve I_c wd = n - S x f / mtot by the adjugate
-  const T S2 = dot(S, S), im = A.inv_mtot;
-  const T a = IO[0] - (S2 - S.x * S.x) * im, bq = IO[1] + (S.x * S.y) * im, c = IO[2] + (S.x * S.z) * im;
-  const T dd = IO[3] - (S2 - S.y * S.y) * im, e = IO[4] + (S.y * S.z) * im, ff = IO[5] - (S2 - S.z * S.z) * im;
-  const V3<T> rhs = n - im * cross(S, f);
-  const T c00 = fma_(dd, ff, -(e * e)), c01 = fma_(c, e, -(bq * ff)), c02 = fma_(bq, e, -(c * dd));
-  const T c11 = fma_(a, ff, -(c * c)), c12 = fma_(bq, c, -(a * e)), c22 = fma_(a, dd, -(bq * bq));
-  const T idet = T(1) / fma_(a, c00, fma_(bq, c01, c * c02));
-  const V3<T> wd{idet * dot3_(c00, c01, c02, rhs.x, rhs.y, rhs.z), idet * dot3_(c01, c11, c12, rhs.x, rhs.y, rhs.z),
-                 idet * dot3_(c02, c12, c22, rhs.x, rhs.y, rhs.z)};
-  const V3<T> Aacc = im * (f + cross(S, wd));
-  const V3<T> vd = mulT(Rq, Aacc);                                   // world acceleration of O
+  V3<T> wd, vd;
+  if constexpr (ROLE == ARM_ROLE_HELPER) {
+    x.sync();                                     // partial sums are in LDS
+    x.sync();                                     // the main wave has solved
+    wd = V3<T>{T(x.get(21)), T(x.get(22)), T(x.get(23))};
+    vd = V3<T>{T(x.get(24)), T(x.get(25)), T(x.get(26))};
+  } else {
+    if constexpr (ROLE == ARM_ROLE_MAIN) {        // link 3 from the helper wave, added exactly as `accumulate` would
+      // The compiler otherwise sinks this wave's own share of the RHS below the barrier (next to its uses), which serialises the
+      // two waves: pin every value it produced so far in front of the barrier.
+      asm volatile("" : "+v"(S.x), "+v"(S.y), "+v"(S.z), "+v"(fb.x), "+v"(fb.y), "+v"(fb.z), "+v"(nb.x), "+v"(nb.y), "+v"(nb.z),
+                        "+v"(IO[0]), "+v"(IO[1]), "+v"(IO[2]), "+v"(IO[3]), "+v"(IO[4]), "+v"(IO[5]));
+      asm volatile("" : "+v"(Rq.m[0]), "+v"(Rq.m[1]), "+v"(Rq.m[2]), "+v"(Rq.m[3]), "+v"(Rq.m[4]), "+v"(Rq.m[5]), "+v"(Rq.m[6]),
+                        "+v"(Rq.m[7]), "+v"(Rq.m[8]));
+      x.sync();
+      S = S + V3<T>{T(x.get(0)), T(x.get(1)), T(x.get(2))};
+      fb = fb + V3<T>{T(x.get(3)), T(x.get(4)), T(x.get(5))};
+      nb = nb + V3<T>{T(x.get(6)), T(x.get(7)), T(x.get(8))} + V3<T>{T(x.get(9)), T(x.get(10)), T(x.get(11))} +
+           V3<T>{T(x.get(12)), T(x.get(13)), T(x.get(14))};
+#pragma unroll
+      for (int q = 0; q < 6; q++) IO[q] += T(x.get(15 + q));
+    }
+    // external wrench about O: rotor thrust / moments, gravity at every CoM
+    V3<T> f = A.mtot * gb - fb;
+    f.z += F;
+    const V3<T> n = M + cross(S, gb) - nb;
+    // I_c = I_O - (|S|^2 1 - S S^T)/mtot ; solve I_c wd = n - S x f / mtot by the adjugate
+    const T S2 = dot(S, S), im = A.inv_mtot;
+    const T a = IO[0] - (S2 - S.x * S.x) * im, bq = IO[1] + (S.x * S.y) * im, c = IO[2] + (S.x * S.z) * im;
+    const T dd = IO[3] - (S2 - S.y * S.y) * im, e = IO[4] + (S.y * S.z) * im, ff = IO[5] - (S2 - S.z * S.z) * im;
+    const V3<T> rhs = n - im * cross(S, f);
+    const T c00 = fma_(dd, ff, -(e * e)), c01 = fma_(c, e, -(bq * ff)), c02 = fma_(bq, e, -(c * dd));
+    const T c11 = fma_(a, ff, -(c * c)), c12 = fma_(bq, c, -(a * e)), c22 = fma_(a, dd, -(bq * bq));
+    const T idet = T(1) / fma_(a, c00, fma_(bq, c01, c * c02));
+    wd = V3<T>{idet * dot3_(c00, c01, c02, rhs.x, rhs.y, rhs.z), idet * dot3_(c01, c11, c12, rhs.x, rhs.y, rhs.z),
+               idet * dot3_(c02, c12, c22, rhs.x, rhs.y, rhs.z)};
+    const V3<T> Aacc = im * (f + cross(S, wd));
+    vd = mulT(Rq, Aacc);                                             // world acceleration of O
+    if constexpr (ROLE == ARM_ROLE_MAIN) {
+      x.put(21, float(wd.x)); x.put(22, float(wd.y)); x.put(23, float(wd.z));
+      x.put(24, float(vd.x)); x.put(25, float(vd.y)); x.put(26, float(vd.z));
+      x.sync();
+    }
+  }
   d[0] = y[3]; d[1] = y[4]; d[2] = y[5];
   d[3] = vd.x; d[4] = vd.y; d[5] = vd.z;
   const T kq = fma_(T(-2), n2, T(2));
@@ -236,14 +296,14 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   for (int k = 0; k < 3; k++) { d[13 + k] = y[16 + k]; d[16 + k] = thdd[k]; }
 }
 
-template <typename AX, typename T, typename PT>
-__device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d) {
-  arm_rhs_body<T, AX>(P, A, y, F, M, cmd, d);
+template <typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, typename T, typename PT>
+__device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{}) {
+  arm_rhs_body<T, AX, PT, ROLE, X>(P, A, y, F, M, cmd, d, x);
 }
 
 // One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states.
-template <typename T, int NROT, int KW, typename AX>
-__device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act) {
+template <typename T, int NROT, int KW, typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg>
+__device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act, const X& x = X{}) {
   const float Ff = (act[0] * P.mass_f) * P.g_f;
   const T u0 = T(Ff), u1 = T(act[1] * P.mscale_f), u2 = T(act[2] * P.mscale_f), u3 = T(act[3] * P.mscale_f);
   T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
@@ -265,16 +325,16 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
     // RK4 with a running weighted sum (acc = k1 + 2 k2 + 2 k3 + k4): four 19-vectors live instead of six -- the fp64
     // build of this kernel otherwise needs more than the 512 registers a wave can have
     T k[19], acc[19], s[19];
-    arm_rhs<AX>(P, A, y, F, M, cmd, k);
+    arm_rhs<AX, ROLE, X>(P, A, y, F, M, cmd, k, x);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = k[i]; s[i] = fma_(hh, k[i], y[i]); }
-    arm_rhs<AX>(P, A, s, F, M, cmd, k);
+    arm_rhs<AX, ROLE, X>(P, A, s, F, M, cmd, k, x);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(hh, k[i], y[i]); }
-    arm_rhs<AX>(P, A, s, F, M, cmd, k);
+    arm_rhs<AX, ROLE, X>(P, A, s, F, M, cmd, k, x);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(h, k[i], y[i]); }
-    arm_rhs<AX>(P, A, s, F, M, cmd, k);
+    arm_rhs<AX, ROLE, X>(P, A, s, F, M, cmd, k, x);
 #pragma unroll
     for (int i = 0; i < 19; i++) y[i] = fma_(h6, acc[i] + k[i], y[i]);
   } while (++it < P.substeps);

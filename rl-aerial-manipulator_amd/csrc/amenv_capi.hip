@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -27,6 +28,7 @@ struct amenv {
   uint32_t tile_bytes = 0;
   int n_tiles = 0;
   int block = 64;
+  bool arm2w = false;              // hexacopter + z,x,x arm at small batches: two-wave step kernel (amenv_kernels.hpp)
   uint64_t steps = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // amenv_step_timed only
   std::string err;
@@ -279,6 +281,16 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   const StepTail tl{io.terminal_obs, io.ep_return, io.ep_len, io.stats};
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
+  if constexpr (NJ == 3 && sizeof(T) == 4) {
+    if (T_steps == 0 && e.arm2w) {   // one tile per 128-thread workgroup: main + helper wave
+      const dim3 g2(e.n_tiles), b2(128);
+      const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + kArmXchgSlots * 64) * sizeof(float);
+      if (timed) hipExtLaunchKernelGGL((step_kernel_arm2w<T, NROT>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
+                                       io.done, io.info, tl, P, C, AA);
+      else hipLaunchKernelGGL((step_kernel_arm2w<T, NROT>), g2, b2, lds2, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C, AA);
+      return hipGetLastError();
+    }
+  }
   if (T_steps > 0) {
     hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C, AA);
   } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
@@ -428,8 +440,15 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     amenv_destroy(e);
     return fail(nullptr, AMENV_ERR_ALLOC, msg);
   }
+  if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32) {
+    // two-wave kernel while the launch is issue-bound (<= 1 wave per SIMD: 32768 envs = 1024 waves on 1024 SIMDs); AMENV_ARM_2WAVE=0/1 overrides
+    const ArmParams<float> ap = make_arm<float>(*e);
+    const char* ov = std::getenv("AMENV_ARM_2WAVE");
+    e->arm2w = !ap.generic_axes && (ov ? ov[0] == '1' : cfg->num_envs <= 32768);
+  }
   char buf[160];
-  std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
+  if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
+  else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                 is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), cfg->vehicle.n_joints ? "v2+arm3" : (is_v1(cfg) ? "v1" : "v2"), e->block);
   e->obs_dim = obs_dim_of(cfg);

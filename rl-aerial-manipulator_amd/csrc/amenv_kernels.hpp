@@ -119,27 +119,26 @@ __device__ __forceinline__ void stage_obs(float* lds_row, const float* o) {
 // Copy the block's staged rows to global memory: consecutive lanes write consecutive float4 (1 KiB per wave instruction).
 // The block's region starts 16-B aligned (blockDim.x * OD * 4 bytes per block, blockDim.x a multiple of 64).
 template <int OD>
-__device__ __forceinline__ void flush_obs(const float* lds, float* __restrict__ obs_block, int rows_valid) {
+__device__ __forceinline__ void flush_obs(const float* lds, float* __restrict__ obs_block, int rows_valid, int bs, int tid) {
   if (rows_valid <= 0) return;   // a workgroup made only of padding lanes publishes nothing
   const float4* s = reinterpret_cast<const float4*>(lds);
   float4* d = reinterpret_cast<float4*>(obs_block);
   const int nflt = rows_valid * OD, nvec = nflt >> 2;
-  const int bs = int(blockDim.x);
   constexpr int PASSES = (OD + 3) / 4;
   // all LDS reads first (unconditional: the staging area always holds blockDim.x rows), then the predicated stores
   float4 v[PASSES];
 #pragma unroll
   for (int j = 0; j < PASSES; j++) {
-    const int f = j * bs + int(threadIdx.x);
+    const int f = j * bs + tid;
     v[j] = (4 * f + 3 < bs * OD) ? s[f] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int j = 0; j < PASSES; j++) {
-    const int f = j * bs + int(threadIdx.x);
+    const int f = j * bs + tid;
     if (f < nvec) d[f] = v[j];
   }
   if constexpr (OD % 4 != 0) {  // a partial last block can leave up to 3 floats past the last full float4
-    const int t = 4 * nvec + int(threadIdx.x);
+    const int t = 4 * nvec + tid;
     if (t < nflt) obs_block[t] = lds[t];
   }
 }
@@ -211,14 +210,15 @@ __device__ __forceinline__ void observe_joints(const Env<T, KW>& e, float* o) { 
   }
 }
 
-template <typename T, int NROT, int KW, int VAR, int NJ>
+template <typename T, int NROT, int KW, int VAR, int NJ, int ROLE = 0, typename X = NoXchg>
 __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const ColdParams& C, const ArmArg<T, NJ>& AA, Env<T, KW>& e, const float* act, int i,
                                               bool active, T& reward, float* o, const StepIO& io, char* tile, int lane,
-                                              bool have_episode, bool& was_reset, int& ep_len_out, float& ep_ret_out) {
+                                              bool have_episode, bool& was_reset, int& ep_len_out, float& ep_ret_out, const X& x = X{}) {
   constexpr int OD = ObsDim<VAR, NJ>::value;
   const int K = KW == 1 ? 1 : P.K;
   if constexpr (NJ > 0) {
-    if (AA.p.generic_axes) dynamics_arm<T, NROT, KW, AxesAny>(P, AA.p, e, act);   // wave-uniform: one of the two bodies runs
+    if constexpr (ROLE != 0) dynamics_arm<T, NROT, KW, AxesZXX, ROLE, X>(P, AA.p, e, act, x);   // two-wave kernel: z,x,x arm only
+    else if (AA.p.generic_axes) dynamics_arm<T, NROT, KW, AxesAny>(P, AA.p, e, act);   // wave-uniform: one of the two bodies runs
     else dynamics_arm<T, NROT, KW, AxesZXX>(P, AA.p, e, act);
   } else { dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]); }
   uint32_t bits;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
   __syncthreads();
   const int row0 = blockIdx.x * BS;
   const int rows = min(BS, hd.n - row0);
-  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, rows);
+  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, rows, BS, int(threadIdx.x));
 #endif
   AMENV_STAMP(5);          // obs flushed
   AMENV_STAMP(6);
@@ -355,6 +355,57 @@ __global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint
   if (lane == 0 && wave < kStampWaves)
     for (int k = 0; k < kStampSlots; k++) io.stats[kStampBase + wave * kStampSlots + k] = stamps_[k];
 #endif
+}
+
+// Two-wave step kernel for the hexacopter + z,x,x arm at small batches (BASELINE config 3 at 4096 envs = 64 tiles).  One tile of 64
+// environments per 128-thread workgroup: wave 0 ("main") does everything the one-wave kernel does except link 3's part of each RHS,
+// wave 1 ("helper") runs the same RK4 on the same state and contributes link 3 (see amenv_arm.hpp).  A launch of 64 lone waves
+// is bound by one wave's instruction issue (~4.8 cycles per dependent VALU op), so halving the longest per-wave instruction
+// stream is what shortens the step; at large batches the one-wave kernel (no redundant work) is used instead.
+// Barriers: both waves execute exactly 8 * substeps + 1 of them, all in uniform control flow.
+template <typename T, int NROT>
+__global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+                                                         float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                         uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C,
+                                                         const ArmArg<T, 3> AA) {
+  constexpr int KW = 1, VAR = VAR_V2, NJ = 3;
+  constexpr int OD = ObsDim<VAR, NJ>::value, AD = kActDim + NJ;
+  const Head hd{blob, tile_bytes, n_envs};
+  const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging, then [kArmXchgSlots][64] exchange
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);   // wave-uniform: 0 main, 1 helper
+  const int i = blockIdx.x * 64 + lane;
+  const bool active = i < hd.n;
+  char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
+  const LdsXchg x{lds + 64 * OD, lane};
+  Env<T, KW> e;
+  load_env<T, KW, NJ>(1, tile, lane, e);
+  float act[AD];
+  const float* ap = reinterpret_cast<const float*>(io.actions) + size_t(min(i, hd.n - 1)) * AD;
+#pragma unroll
+  for (int j = 0; j < AD; j++) act[j] = ap[j];
+  if (role != 0) {
+    dynamics_arm<T, NROT, KW, AxesZXX, ARM_ROLE_HELPER, LdsXchg>(P, AA.p, e, act, x);
+    __syncthreads();   // pairs with the main wave's barrier in front of the observation flush
+    return;
+  }
+  T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
+  uint32_t bits = step_lane<T, NROT, KW, VAR, NJ, ARM_ROLE_MAIN, LdsXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset,
+                                                                        ep_len, ep_ret, x);
+  const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+  accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
+  store_env_step<T, KW>(tile, lane, e);
+  store_env_episode<T, KW, NJ>(1, tile, lane, e);
+  if (active) {
+    reinterpret_cast<T*>(io.reward)[i] = reward;
+    io.done[i] = is_done ? 1 : 0;
+    io.info[i] = bits;
+  }
+  stage_obs<OD>(lds + lane * OD, o);
+  __syncthreads();
+  const int row0 = blockIdx.x * 64;
+  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
 }
 
 // n_steps control steps per launch with open-loop actions [T][N][4]; per-step outputs [T][N]...
@@ -404,7 +455,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
     if (io.obs) {
       stage_obs<OD>(lds + threadIdx.x * OD, o);
       __syncthreads();
-      flush_obs<OD>(lds, io.obs + (size_t(t) * n + row0) * OD, rows);
+      flush_obs<OD>(lds, io.obs + (size_t(t) * n + row0) * OD, rows, int(blockDim.x), int(threadIdx.x));
       __syncthreads();
     }
   }

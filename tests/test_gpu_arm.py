@@ -46,7 +46,7 @@ def test_arm_dims_and_reset():
     import rl_aerial_manipulator_amd as amd
     n = 1000
     env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=5)
-    assert (env.obs_dim, env.act_dim, env.n_float_fields) == (26, 7, 25) and "arm3" in env.kernel_name
+    assert (env.obs_dim, env.act_dim, env.n_float_fields) == (26, 7, 25) and "arm" in env.kernel_name
     orc = orc_arm(n, seed=5)
     obs = env.reset().cpu().numpy(); oobs = orc.reset()
     f, i = gpu_state(env)
@@ -153,3 +153,32 @@ def test_arm_rollout_equals_steps_and_vecenv():
     o, r, d, inf = ve.step(np.tile(np.array([1, 0, 0, 0, 0.2, -0.2, 0.1], np.float32), (64, 1)))
     assert o.shape == (64, 26) and np.isfinite(o).all()
     e1.close(); e2.close(); ve.close()
+
+
+def test_two_wave_kernel_is_bit_identical_to_one_wave_kernel(monkeypatch):
+    """Small batches run step_kernel_arm2w (main + helper wave per 64-env tile, link 3 on the helper); its partial sums are
+    added in the one-wave kernel's order, so whole trajectories -- resets, rewards, observations included -- are identical."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("AMENV_ARM_2WAVE", flag)
+        env = amd.GpuWaypointEnv(300, vehicle="hexa_arm", seed=9)
+        assert ("arm2w" in env.kernel_name) == (flag == "1")
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(5)
+        acts = torch.randn(400, 300, 7, device="cuda", generator=g) * 0.3
+        acts[..., 0] += 1.0
+        acts[:, ::7, 0] = 0.2                      # some envs fall: crashes and auto-resets inside the window
+        acts = acts.clamp(-1, 2)
+        rec = []
+        for t in range(400):
+            obs, rew, done, info = env.step(acts[t])
+            rec.append((obs.clone(), rew.clone(), done.clone(), info.clone()))
+        f, i = env.get_state()
+        outs.append((rec, f.clone(), i.clone(), env.stats()))
+        env.close()
+    (r0, f0, i0, s0), (r1, f1, i1, s1) = outs
+    assert torch.equal(f0, f1) and torch.equal(i0, i1) and s0 == s1 and s0["episodes"] > 20
+    for (o0, w0, d0, b0), (o1, w1, d1, b1) in zip(r0, r1):
+        assert torch.equal(o0, o1) and torch.equal(w0, w1) and torch.equal(d0, d1) and torch.equal(b0, b1)
