@@ -178,7 +178,7 @@ def main():
                      "timing": f"mean of {pairs} launches, HIP start/stop events stamped by the kernel dispatch (amenv_step_timed)",
                      "kernel_us_min": min(per), "kernel_us_median": sorted(per)[len(per) // 2],
                      "achieved_loop": n * bytes_step / (dev_ms / K * 1e-3) / 1e9,
-                     "note": f"{n} envs = {(n + 63) // 64} wavefronts on 256 CUs, {n * bytes_step / 1e6:.2f} MB algorithmic per launch"
+                     "note": f"{n} envs = {(n + 63) // 64 * (2 if 'arm2w' in env.kernel_name else 1)} wavefronts on 256 CUs, {n * bytes_step / 1e6:.2f} MB algorithmic per launch"
                              + ("; latency-bound by construction (dependent-launch floor on this box 1.66 us, SURVEY 7.3-4)" if n <= 65536 else "")},
         "device_ms_per_step": dev_ms / K,
         "episodes_finished_rank0": stats["episodes"],
