@@ -76,16 +76,17 @@ class _QuadcopterView:
 
 
 class WaypointQuadEnv(_Base):
+    TASK = "v2"   # which reference env file this class stands for; the v1 facades (compat/v1/) override it
+
     def __init__(self, device=0, seed=0, backend=None, **env_kwargs):
         if _Base is not object:
             super().__init__()
-        from importlib import import_module
-        spaces = import_module("rl_aerial_manipulator_amd").vec_env.make_spaces()
-        self.observation_space, self.action_space = spaces
         self._seed = seed
         self._kw = dict(env_kwargs)
+        self._kw.setdefault("task", self.TASK)
         self._device = device
         self._b = backend if backend is not None else _amd.GpuWaypointEnv(1, device=device, seed=seed, auto_reset=False, **self._kw)
+        self.observation_space, self.action_space = _amd.vec_env.make_spaces(getattr(self._b, "obs_dim", 20), 4)
         self.dt = 1.0 / 200.0
         self.max_episode_steps = int(self._b.cfg.task.max_episode_steps)
         self.counter_limit = int(self._b.cfg.task.counter_limit)
@@ -108,13 +109,15 @@ class WaypointQuadEnv(_Base):
 
     @property
     def waypoint_list(self):
-        f = self._blob()[0]
+        f, i = self._blob()
         K = int(self._b.cfg.task.num_waypoints)
+        if int(self._b.cfg.task.variant) != _L.TASK_V2_SCALED20:   # v1: 1..2 waypoints drawn per episode (flags bits 4-7)
+            K = (int(i[_L.I_FLAGS]) >> 4) & 15
         return [f[_L.F_WP0 + 3 * k:_L.F_WP0 + 3 * k + 3].copy() for k in range(K)]
 
     @property
     def waypoint_index(self):
-        return int(self._blob()[1][_L.I_FLAGS]) & 255
+        return int(self._blob()[1][_L.I_FLAGS]) & 15
 
     @property
     def current_waypoint(self):

@@ -7,14 +7,14 @@ from oracle import oracle as O
 
 
 class OracleBackend:
-    def __init__(self, num_envs, seed=0, auto_reset=True, num_waypoints=1, max_episode_steps=None):
+    def __init__(self, num_envs, seed=0, auto_reset=True, num_waypoints=1, max_episode_steps=None, variant=O.TASK_V2_SCALED20):
         self.cfg = O.reference_quad_config(num_envs=num_envs, seed=seed, flags=O.FLAG_AUTO_RESET if auto_reset else 0,
-                                           num_waypoints=num_waypoints)
+                                           num_waypoints=num_waypoints, variant=variant)
         if max_episode_steps is not None:
             self.cfg.task.max_episode_steps = max_episode_steps
         self.env = O.OracleEnv(self.cfg)
-        self.num_envs, self.obs_dim, self.act_dim = num_envs, 20, 4
-        self.terminal_obs = torch.zeros(num_envs, 20)
+        self.num_envs, self.obs_dim, self.act_dim = num_envs, self.env.obs_dim, 4
+        self.terminal_obs = torch.zeros(num_envs, self.obs_dim)
         self.ep_return = torch.zeros(num_envs)
         self.ep_len = torch.zeros(num_envs, dtype=torch.int32)
 

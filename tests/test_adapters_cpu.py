@@ -4,6 +4,7 @@ episode records, the attribute surface the reference's visualiser reads) against
 import os
 import sys
 
+import pytest
 import numpy as np
 
 import rl_aerial_manipulator_amd as amd
@@ -90,3 +91,35 @@ def test_facade_replays_golden_episode_like_the_reference():
     assert wf.shape == (3, 6) and np.allclose(wf[:, 4], env.quadcopter.position())
     assert np.allclose(np.linalg.norm(wf[:, 0] - wf[:, 4]), 0.086) and len(env.quadcopter.attitude()) == 3
     assert np.allclose(env.current_waypoint, d["waypoints"][0]) and abs(env.final_yaw - float(d["final_yaw"])) < 1e-12
+
+
+@pytest.mark.parametrize("module,variant,gold", [("rl_env", "TASK_V1_RAW17", "v1r_reach2"), ("rl_env_scaledObs", "TASK_V1_SCALED17", "v1s_reach2")])
+def test_v1_facades_replay_golden_episodes(module, variant, gold):
+    """`from rl_env import WaypointQuadEnv` (v1/rl_train_vecN.py:5) / `from rl_env_scaledObs import ...` (v1/rl_train.py:4)
+    resolve to compat/v1/: 17-D observations, two waypoints in this episode, +400 termination on the last one."""
+    import importlib.util
+    from oracle import oracle as O
+    path = os.path.join(ROOT, "rl-aerial-manipulator_amd", "compat", "v1", module + ".py")
+    spec = importlib.util.spec_from_file_location("_v1_facade_" + module, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = G.load(gold)
+    be = OracleBackend(1, auto_reset=False, variant=getattr(O, variant))
+    env = mod.WaypointQuadEnv(backend=be)
+    assert env.TASK.startswith("v1") and env.observation_space.shape == (17,)
+    obs, info = env.reset()
+    assert obs.shape == (17,) and obs.dtype == np.float32 and info == {} and len(env.waypoint_list) in (1, 2)
+    f, i = be.get_state()
+    f, i = f.numpy().copy(), i.numpy().copy()
+    G.fill_blob(f, i, {**d, "actions": d["actions"][:1]}, per_env_k=True)
+    be.set_state(f, i)
+    env._cache = None
+    assert len(env.waypoint_list) == 2 and np.allclose(env.waypoint_list[1], d["waypoints"][1])
+    assert np.array_equal(env._get_observation(), d["obs0"])
+    T = d["actions"].shape[0]
+    for t in range(T):
+        obs, r, term, trunc, info = env.step(d["actions"][t])
+        assert (term, trunc) == (bool(d["terminated"][t]), bool(d["truncated"][t]))
+        assert np.abs(obs - d["obs"][t]).max() < 5e-3 * max(1.0, np.abs(d["obs"][t]).max())      # free-running
+        assert env.waypoint_index == d["var_waypoint_index"][t + 1] and env.current_step == d["var_current_step"][t + 1]
+    assert term and info.get("success") is True
