@@ -39,6 +39,8 @@ def main():
     model.learn(a.timesteps, log_fn=show)
     if sh.rank == 0:
         print("saved", model.save(a.save))
+        mean_reward, std_reward = amd.evaluate_policy(model, env, n_eval_episodes=max(10, a.envs))      # rl_train.py:60-61
+        print(f"Mean reward: {mean_reward} +/- {std_reward}")
     if dist is not None:
         dist.destroy_process_group()
 

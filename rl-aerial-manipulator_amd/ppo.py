@@ -510,3 +510,35 @@ class PPO:
                     raise L.AmenvError(f"{k}: checkpoint shape {tuple(sd[k].shape)} != policy {tuple(v.shape)}")
                 v.copy_(torch.as_tensor(sd[k]).to(v.device))
         return self
+
+
+@torch.no_grad()
+def evaluate_policy(model, env, n_eval_episodes=10, deterministic=True, check_every=64, max_steps=None):
+    """SB3 `evaluate_policy(model, env, n_eval_episodes)` (v2/rl_train.py:60) on the batched env: every env contributes the
+    same number of episodes (ceil(n / num_envs), SB3's rule for vectorised envs), returns (mean, std) of the episode returns.
+    `model`: a `PPO`, an `ActorCritic` or anything with `.predict(obs, deterministic)`.  The loop stays on the device; the host
+    looks at the completion counters once every `check_every` steps."""
+    n = env.num_envs
+    per_env = -(-int(n_eval_episodes) // n)
+    obs = env.reset()
+    counts = torch.zeros(n, dtype=torch.int64, device=obs.device)
+    total = torch.zeros(n, dtype=torch.float64, device=obs.device)
+    total_sq = torch.zeros_like(total)
+    lengths = torch.zeros(n, dtype=torch.int64, device=obs.device)
+    limit = max_steps if max_steps is not None else per_env * (int(env.cfg.task.max_episode_steps) + 2)
+    for t in range(limit):
+        obs, _, done, _ = env.step(model.predict(obs, deterministic))
+        take = (done != 0) & (counts < per_env)
+        r = env.ep_return.to(torch.float64)
+        total += torch.where(take, r, torch.zeros_like(r))
+        total_sq += torch.where(take, r * r, torch.zeros_like(r))
+        lengths += torch.where(take, env.ep_len.to(torch.int64), torch.zeros_like(lengths))
+        counts += take.to(torch.int64)
+        if (t + 1) % check_every == 0 and bool((counts >= per_env).all()):
+            break
+    k = int(counts.sum())
+    if k == 0:
+        raise L.AmenvError("evaluate_policy: no episode finished within the step limit")
+    mean = float(total.sum()) / k
+    var = max(float(total_sq.sum()) / k - mean * mean, 0.0)
+    return mean, math.sqrt(var)

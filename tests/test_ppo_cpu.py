@@ -251,3 +251,30 @@ def test_tall_skinny_linear_gradients_match_nn_linear():
     assert torch.allclose(lin.weight.grad, w.grad, rtol=1e-11, atol=1e-11)
     assert torch.allclose(lin.bias.grad, b.grad, rtol=1e-11, atol=1e-11)
     assert torch.allclose(x.grad, x2.grad, rtol=1e-11, atol=1e-11)
+
+
+def test_evaluate_policy_counts_episodes_like_sb3():
+    """evaluate_policy on the oracle-backed stand-in env: every env contributes ceil(n_eval / num_envs) episodes; mean / std of
+    their returns (population std, as np.std in SB3)."""
+    from rl_aerial_manipulator_amd.ppo import evaluate_policy
+    from tests.oracle_backend import OracleBackend
+    pol = ActorCritic.from_sb3(fixture_state_dict())
+    env = OracleBackend(8, seed=4)
+    seen = []
+    step = env.step
+
+    def spy(a):
+        out = step(a)
+        d = out[2].numpy().astype(bool)
+        seen.extend((i, float(env.ep_return[i])) for i in np.nonzero(d)[0])
+        return out
+    env.step = spy
+    mean, std = evaluate_policy(pol, env, n_eval_episodes=10, check_every=16)     # -> 2 episodes per env
+    first = {}
+    for i, r in seen:
+        first.setdefault(i, [])
+        if len(first[i]) < 2:
+            first[i].append(r)
+    rs = np.array([r for v in first.values() for r in v])
+    assert len(rs) == 16 and abs(mean - rs.mean()) < 1e-6 * abs(rs.mean()) and abs(std - rs.std()) < 1e-3 * max(1.0, rs.std())
+    assert 10000 < mean < 26000
