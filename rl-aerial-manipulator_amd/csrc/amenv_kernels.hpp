@@ -224,8 +224,14 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   uint32_t bits;
   if constexpr (VAR == VAR_V1) { bits = task_step_v1<T, KW>(P, e, reward); } else { bits = task_step<T, KW>(P, e, reward); }
   e.ep_return += reward;
-  if constexpr (VAR == VAR_V1) { observe_v1<T, KW>(P.raw_obs != 0, e, o); } else { observe<T, KW>(K, e, o); }
-  if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
+  // two-wave kernel: the helper wave computes and publishes the observation of every lane; this (main) wave forms one only in the
+  // cold path below (terminal observation / post-reset observation of the lanes whose episode ended)
+  constexpr bool kLazyObs = ROLE == ARM_ROLE_MAIN;
+  auto obs_now = [&]() {
+    if constexpr (VAR == VAR_V1) { observe_v1<T, KW>(P.raw_obs != 0, e, o); } else { observe<T, KW>(K, e, o); }
+    if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
+  };
+  if constexpr (!kLazyObs) obs_now();
   was_reset = false;
   ep_len_out = 0; ep_ret_out = 0.0f;
   const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
@@ -234,6 +240,7 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
     uint32_t r[12];
     reset_words_wave(C, resets, C.gid0 + i, e.episode, r);  // all lanes take part, lanes 0..2 do the work
     if (ended) {  // SB3 DummyVecEnv + Monitor contract
+      if constexpr (kLazyObs) obs_now();
       ep_len_out = e.step; ep_ret_out = float(e.ep_return);
       if (active) {
         if (io.terminal_obs) {
@@ -386,8 +393,18 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
 #pragma unroll
   for (int j = 0; j < AD; j++) act[j] = ap[j];
   if (role != 0) {
+    // helper: link 3's share of the RK4, then the observation of every lane (a pure function of the post-step state for the
+    // single-waypoint task), staged in LDS and flushed coalesced -- all off the main wave's critical path
     dynamics_arm<T, NROT, KW, AxesZXX, ARM_ROLE_HELPER, LdsXchg>(P, AA.p, e, act, x);
-    __syncthreads();   // pairs with the main wave's barrier in front of the observation flush
+    float ho[kObsDimMax];
+    observe<T, KW>(1, e, ho);
+    observe_joints<T, KW>(e, ho);
+    stage_obs<OD>(lds + lane * OD, ho);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();          // one wave stages and flushes: LDS accesses of a wave complete in order
+    const int row0h = blockIdx.x * 64;
+    flush_obs<OD>(lds, io.obs + size_t(row0h) * OD, min(64, hd.n - row0h), 64, lane);
+    __syncthreads();   // stores acknowledged (s_waitcnt vmcnt(0)) before the main wave may overwrite the rows of reset lanes
     return;
   }
   T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
@@ -402,10 +419,12 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
     io.done[i] = is_done ? 1 : 0;
     io.info[i] = bits;
   }
-  stage_obs<OD>(lds + lane * OD, o);
-  __syncthreads();
-  const int row0 = blockIdx.x * 64;
-  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
+  __syncthreads();     // the helper's observation rows have landed
+  if (was_reset && active) {   // rare: this lane's env was auto-reset -> its row must hold the post-reset observation
+    float* d = io.obs + size_t(i) * OD;
+#pragma unroll
+    for (int j = 0; j < OD; j++) d[j] = o[j];
+  }
 }
 
 // n_steps control steps per launch with open-loop actions [T][N][4]; per-step outputs [T][N]...
