@@ -533,3 +533,70 @@ def test_v1_rollout_equals_steps_and_vecenv_shape(amd):
     ve = amd.GpuVecEnv(num_envs=64, task="v1_raw")
     assert ve.observation_space.shape == (17,) and ve.reset().shape == (64, 17)
     e1.close(); e2.close(); ve.close()
+
+
+# ---- the other rigid vehicles: 6-rotor kernel (BASELINE configs[1]) and the generic runtime-rotor-count kernel --------------
+def _vehicle_config(amd, vehicle, n):
+    """`hexa`: the repo's hexacopter (SDF-derived, tools/hexa_params.py).  `octo`: a synthetic 8-rotor vehicle that exercises the
+    NROT = AMENV_MAX_ROTORS instantiation: rotors on a 0.3 m circle every 45 deg, alternating spin, pseudo-inverse allocation."""
+    if vehicle == "hexa":
+        return amd._lib.default_config("hexa", n)
+    cfg = amd._lib.default_config("hexa", n)
+    v = cfg.vehicle
+    v.n_rotors, v.mass = 8, 3.0
+    I = np.diag([0.05, 0.055, 0.09]); I[0, 2] = I[2, 0] = 1e-3
+    ang = np.arange(8) * np.pi / 4
+    mix = np.stack([np.ones(8), 0.3 * np.sin(ang), -0.3 * np.cos(ang), 0.02 * (-1.0) ** np.arange(8)])   # [4, 8]: F, Mx, My, Mz per unit thrust
+    alloc = np.linalg.pinv(mix)                                                                          # [8, 4]
+    for k, val in enumerate(I.reshape(-1)): v.inertia[k] = val
+    for k, val in enumerate(np.linalg.inv(I).reshape(-1)): v.inv_inertia[k] = val
+    for r in range(8):
+        for j in range(4):
+            v.alloc[r * 4 + j] = alloc[r, j]
+            v.mix[j * 8 + r] = mix[j, r]
+        v.t_min[r], v.t_max[r] = 0.0, 2.0 * v.mass * v.g / 8
+    v.moment_scale = 1.0
+    return cfg
+
+
+@pytest.mark.parametrize("vehicle", ["hexa", "octo"])
+@pytest.mark.parametrize("dtype,tol", [("f32", REL32), ("f64", ABS64)])
+def test_other_rigid_vehicles_teacher_forced_vs_oracle(amd, vehicle, dtype, tol):
+    """Same closed loop as for the reference quadrotor, for the hexacopter parameters (no reference dynamics exist for them:
+    parity unpinned, the oracle with the same parameters is the check) and for an 8-rotor vehicle."""
+    import ctypes as C
+    torch = _torch()
+    n = 1024
+    cfg = _vehicle_config(amd, vehicle, n)
+    cfg.seed, cfg.dtype = 7, (amd._lib.F64 if dtype == "f64" else amd._lib.F32)
+    env = amd.GpuWaypointEnv(n, config=cfg)
+    assert f"NROT={6 if vehicle == 'hexa' else 8}" in env.kernel_name
+    ocfg = O.reference_quad_config(num_envs=n, seed=7)
+    C.memmove(C.byref(ocfg.vehicle), C.byref(cfg.vehicle), C.sizeof(O.Vehicle))
+    orc = O.OracleEnv(ocfg)
+    obs = env.reset().cpu().numpy(); oobs = orc.reset()
+    f, i = gpu_state(env)
+    assert np.array_equal(f, orc.fstate) and np.array_equal(i, orc.istate)
+    np.testing.assert_allclose(obs, oobs, rtol=OBS_ULP, atol=1e-9)
+    rng = np.random.RandomState(3)
+    worst = 0.0; flips = 0; dones = 0; sat = 0
+    for t in range(250):
+        a = rng.uniform([0, -1, -1, -1], [2, 1, 1, 1], (n, 4)).astype(np.float32)
+        a[:, 1:] *= 0.3 if t % 50 < 5 else 0.03          # bursts of large moments: the per-rotor clamp binds
+        a[::9, 0] = 0.1                                  # some envs fall: crash + auto-reset
+        f, i = gpu_state(env)
+        orc.fstate[:] = f; orc.istate[:] = i
+        _, rew, done, info = env.step(torch.from_numpy(a).cuda())
+        out = orc.step(a)
+        f2, i2 = gpu_state(env)
+        gi = info.cpu().numpy().view(np.uint32)
+        bad = (gi & 127) != (out["info"] & 127)
+        flips += int(bad.sum())
+        nd = ~bad & (out["done"] == 0)
+        worst = max(worst, rel_err(f2[0:13][:, nd], orc.fstate[0:13][:, nd]).max())
+        dn = ~bad & (out["done"] != 0)
+        dones += int(dn.sum())
+        assert np.array_equal(f2[:, dn], orc.fstate[:, dn]) and np.array_equal(i2[:, ~bad], orc.istate[:, ~bad])
+    assert worst < tol, worst
+    assert flips <= 3 and dones > 100, (flips, dones)
+    env.close()
