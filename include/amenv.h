@@ -23,6 +23,7 @@
 #ifndef AMENV_H_
 #define AMENV_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -283,6 +284,18 @@ int amenv_gae(const float* rewards, const float* values, const uint8_t* dones, c
  * act_dim (4 or 7).  z from Philox4x32-10 keyed by (seed, env_id_offset + i, draw): pass a different `draw` per call. */
 int amenv_gaussian_act(const float* mean, const float* log_std, const float* low, const float* high, float* raw, float* clipped,
                        float* logp, int64_t n_envs, int32_t act_dim, uint64_t seed, uint32_t draw, int64_t env_id_offset, void* stream);
+/* The part of SB3's PPO.train between the network outputs and the backward pass, fused (three launches instead of ~60 torch
+ * kernels): per-minibatch advantage normalisation (mean, unbiased std, eps 1e-8), Gaussian log-prob of `actions` under
+ * (mean, log_std), ratio to old_logp, clipped surrogate, value MSE, entropy bonus -- and the gradient of
+ *   L = policy_loss + ent_coef * entropy_loss + vf_coef * value_loss
+ * with respect to mean [n, act_dim], value [n] and log_std [act_dim] (act_dim 4 or 7).  stats4 = {policy_loss, value_loss,
+ * entropy_loss, clip_fraction}.  Deterministic (fixed-order reductions, no atomics).  workspace: device buffer of
+ * amenv_ppo_workspace_bytes() bytes, 8-byte aligned.  Hyper-parameters of the reference: clip .2, ent 5e-4, vf .5 (v2/rl_train.py:38-53). */
+size_t amenv_ppo_workspace_bytes(void);
+int amenv_ppo_loss_grad(const float* mean, const float* value, const float* log_std, const float* actions, const float* old_logp,
+                        const float* advantages, const float* returns, int64_t n, int32_t act_dim, float clip_range, float ent_coef,
+                        float vf_coef, int32_t normalize_advantage, float* d_mean, float* d_value, float* d_log_std, float* stats4,
+                        void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -441,10 +442,10 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     return fail(nullptr, AMENV_ERR_ALLOC, msg);
   }
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32) {
-    // two-wave kernel while the launch is issue-bound (<= 1 wave per SIMD: 32768 envs = 1024 waves on 1024 SIMDs); AMENV_ARM_2WAVE=0/1 overrides
+    // two-wave kernel while the launch is issue-bound (measured faster up to 65536 envs: 18.0 vs 19.5 us); AMENV_ARM_2WAVE=0/1 overrides
     const ArmParams<float> ap = make_arm<float>(*e);
     const char* ov = std::getenv("AMENV_ARM_2WAVE");
-    e->arm2w = !ap.generic_axes && (ov ? ov[0] == '1' : cfg->num_envs <= 32768);
+    e->arm2w = !ap.generic_axes && (ov ? ov[0] == '1' : cfg->num_envs <= 65536);
   }
   char buf[160];
   if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
@@ -692,6 +693,31 @@ int amenv_gaussian_act(const float* mean, const float* log_std, const float* low
     case 7: hipLaunchKernelGGL(gaussian_act_kernel<7>, grid, block, 0, (hipStream_t)stream, mean, log_std, low, high, raw, clipped, logp, (int64_t)n_envs, s_lo, s_hi, draw, (int64_t)env_id_offset); break;
     default: return AMENV_ERR_INVALID;   // 4 = quad/hexa, 7 = hexa + 3 joints
   }
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+size_t amenv_ppo_workspace_bytes(void) { return size_t(kPpoMaxBlocks) * (2 * sizeof(double) + kPpoPartial * sizeof(float)); }
+
+int amenv_ppo_loss_grad(const float* mean, const float* value, const float* log_std, const float* actions, const float* old_logp,
+                        const float* advantages, const float* returns, int64_t n, int32_t act_dim, float clip_range, float ent_coef,
+                        float vf_coef, int32_t normalize_advantage, float* d_mean, float* d_value, float* d_log_std, float* stats4,
+                        void* workspace, void* stream) {
+  if (!mean || !value || !log_std || !actions || !old_logp || !advantages || !returns || !d_mean || !d_value || !d_log_std || !stats4 ||
+      !workspace || n <= 0 || !(clip_range >= 0.0f) || (reinterpret_cast<uintptr_t>(workspace) & 7u))
+    return AMENV_ERR_INVALID;
+  const int blocks = int(std::min<int64_t>(kPpoMaxBlocks, (n + kPpoBlock - 1) / kPpoBlock));
+  double* adv_part = static_cast<double*>(workspace);
+  float* part = reinterpret_cast<float*>(adv_part + 2 * kPpoMaxBlocks);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ppo_adv_partials, dim3(blocks), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part);
+  switch (act_dim) {
+    case 4: hipLaunchKernelGGL(ppo_loss_grad<4>, dim3(blocks), dim3(kPpoBlock), 0, s, mean, value, log_std, actions, old_logp, advantages, returns,
+                               (int64_t)n, clip_range, vf_coef, (int)normalize_advantage, (const double*)adv_part, blocks, d_mean, d_value, part); break;
+    case 7: hipLaunchKernelGGL(ppo_loss_grad<7>, dim3(blocks), dim3(kPpoBlock), 0, s, mean, value, log_std, actions, old_logp, advantages, returns,
+                               (int64_t)n, clip_range, vf_coef, (int)normalize_advantage, (const double*)adv_part, blocks, d_mean, d_value, part); break;
+    default: return AMENV_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(ppo_finalize, dim3(1), dim3(64), 0, s, (const float*)part, blocks, (int)act_dim, (int64_t)n, log_std, ent_coef, d_log_std, stats4);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

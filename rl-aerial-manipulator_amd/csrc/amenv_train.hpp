@@ -85,4 +85,123 @@ __global__ __launch_bounds__(256) void gaussian_act_kernel(const float* __restri
   logp[i] = lp;
 }
 
+
+// ---- fused PPO loss and its gradient (SB3 PPO.train, the part between the network outputs and the backward pass) ----------
+// torch expresses it as ~60 elementwise / reduction kernels per minibatch (advantage normalisation, Gaussian log-prob, ratio,
+// clipped surrogate, value MSE, entropy and the backward of each), ~5 us apiece inside a replayed graph = a quarter of the update
+// at 65,536 samples.  Here: three launches.
+//   1. ppo_adv_partials : per-block fp64 sum / sum of squares of the raw advantages
+//   2. ppo_loss_grad    : every block reduces those partials itself (fixed order) -> mean, 1/(std + 1e-8) (unbiased std, as
+//                         torch.std); one lane per sample: d loss / d mean[i,:], d loss / d value[i]; per-block partials of
+//                         d loss / d log_std[:] and of the four reported scalars
+//   3. ppo_finalize     : fixed-order sum of the per-block partials (deterministic, no atomics)
+// Loss (SB3 2.6.0): L = mean(-min(A r, A clip(r, 1-c, 1+c))) + ent_coef * (-mean(entropy)) + vf_coef * mean((R - V)^2),
+// r = exp(logp - logp_old), A normalised per minibatch.  torch.min's backward splits ties evenly between its arguments and
+// clamp passes gradient on the closed interval, which together give: d/dr = -A where r is inside [1-c, 1+c] or where the
+// unclipped term is the smaller one, else 0.
+constexpr int kPpoBlock = 256;
+constexpr int kPpoMaxBlocks = 1024;
+constexpr int kPpoPartial = AMENV_MAX_JOINTS + kActDim + 4;   // d log_std[<=7] + policy / value / clip-fraction sums (+1 spare)
+
+__global__ __launch_bounds__(kPpoBlock) void ppo_adv_partials(const float* __restrict__ adv, int64_t n, double* __restrict__ part) {
+  __shared__ double sh[2][kPpoBlock / 64];
+  double s = 0.0, q = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * kPpoBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kPpoBlock) {
+    const double a = adv[i];
+    s += a; q += a * a;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); q += __shfl_down(q, o); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double S = 0.0, Q = 0.0;
+    for (int k = 0; k < kPpoBlock / 64; k++) { S += sh[0][k]; Q += sh[1][k]; }
+    part[2 * blockIdx.x] = S; part[2 * blockIdx.x + 1] = Q;
+  }
+}
+
+template <int A>
+__global__ __launch_bounds__(kPpoBlock) void ppo_loss_grad(const float* __restrict__ mean, const float* __restrict__ value,
+                                                           const float* __restrict__ log_std, const float* __restrict__ actions,
+                                                           const float* __restrict__ old_logp, const float* __restrict__ adv,
+                                                           const float* __restrict__ ret, int64_t n, float clip, float vf_coef,
+                                                           int normalize, const double* __restrict__ adv_part, int adv_blocks,
+                                                           float* __restrict__ d_mean, float* __restrict__ d_value,
+                                                           float* __restrict__ part) {
+  __shared__ float sh[kPpoBlock / 64][kPpoPartial];
+  // advantage statistics: every block sums the (few hundred) partials in the same fixed order
+  float mu = 0.0f, inv_sd = 1.0f;
+  if (normalize && n > 1) {
+    double S = 0.0, Q = 0.0;
+    for (int k = 0; k < adv_blocks; k++) { S += adv_part[2 * k]; Q += adv_part[2 * k + 1]; }
+    const double m = S / double(n);
+    const double var = fmax((Q - S * m) / double(n - 1), 0.0);
+    mu = float(m);
+    inv_sd = 1.0f / (float(sqrt(var)) + 1e-8f);
+  }
+  float els[A], isd[A];
+#pragma unroll
+  for (int k = 0; k < A; k++) { els[k] = log_std[k]; isd[k] = expf(-els[k]); }
+  const float inv_n = 1.0f / float(n);
+  float acc[kPpoPartial];
+#pragma unroll
+  for (int k = 0; k < kPpoPartial; k++) acc[k] = 0.0f;
+  for (int64_t i = int64_t(blockIdx.x) * kPpoBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kPpoBlock) {
+    float z[A], lp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < A; k++) {
+      z[k] = (actions[i * A + k] - mean[i * A + k]) * isd[k];
+      lp += fma_(-0.5f * z[k], z[k], -els[k]) - 0.918938533204672742f;
+    }
+    const float r = expf(lp - old_logp[i]);
+    const float a = (adv[i] - mu) * inv_sd;
+    const float s1 = a * r, s2 = a * fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
+    const bool inside = r >= 1.0f - clip && r <= 1.0f + clip;
+    const float g_lp = (inside || s1 < s2) ? -a * r * inv_n : 0.0f;          // d L / d logp_i
+#pragma unroll
+    for (int k = 0; k < A; k++) {
+      d_mean[i * A + k] = g_lp * z[k] * isd[k];
+      acc[k] += g_lp * fma_(z[k], z[k], -1.0f);
+    }
+    const float dv = ret[i] - value[i];
+    d_value[i] = -2.0f * vf_coef * dv * inv_n;
+    acc[A] += -fminf(s1, s2);
+    acc[A + 1] += dv * dv;
+    acc[A + 2] += fabsf(r - 1.0f) > clip ? 1.0f : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < A + 3; k++)
+    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_down(acc[k], o);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < A + 3; k++) sh[w][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < A + 3) {
+    float t = 0.0f;
+    for (int k = 0; k < kPpoBlock / 64; k++) t += sh[k][threadIdx.x];
+    part[blockIdx.x * kPpoPartial + threadIdx.x] = t;
+  }
+}
+
+// d_log_std[k] = sum of partials + ent_coef * d(-mean entropy)/d log_std = ... - ent_coef ; stats = {policy loss, value loss,
+// entropy loss, clip fraction}
+__global__ void ppo_finalize(const float* __restrict__ part, int blocks, int A, int64_t n, const float* __restrict__ log_std, float ent_coef,
+                             float* __restrict__ d_log_std, float* __restrict__ stats) {
+  const int k = threadIdx.x;
+  if (k >= A + 3) return;
+  float t = 0.0f;
+  for (int b = 0; b < blocks; b++) t += part[b * kPpoPartial + k];
+  if (k < A) d_log_std[k] = t - ent_coef;
+  else if (k == A) stats[0] = t / float(n);
+  else if (k == A + 1) stats[1] = t / float(n);
+  else {
+    stats[3] = t / float(n);
+    float e = 0.0f;
+    for (int j = 0; j < A; j++) e += 1.418938533204672742f + log_std[j];
+    stats[2] = -e;
+  }
+}
+
 }  // namespace amenv_dev

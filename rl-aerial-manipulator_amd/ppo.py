@@ -19,6 +19,7 @@ import ctypes as C
 import io
 import json
 import math
+import os
 import zipfile
 
 import torch
@@ -27,7 +28,7 @@ from torch import nn
 from . import _lib as L
 
 
-_SPLIT = 256   # rows per partial product of the weight gradient
+_SPLIT = int(os.environ.get("AMENV_PPO_SPLIT", "256"))   # rows per partial product of the weight gradient (tuning override)
 
 
 class _TallSkinnyLinearFn(torch.autograd.Function):
@@ -238,7 +239,7 @@ class MinibatchStep:
     all-reduce of the flat gradient buffer.  A ragged last minibatch (n % batch_size) always runs eagerly."""
 
     def __init__(self, policy, optimizer, *, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5,
-                 normalize_advantage=True, dist=None, use_graph=None, split_graphs=None):
+                 normalize_advantage=True, dist=None, use_graph=None, split_graphs=None, fused_loss=None):
         if policy.flat_grad is None:
             policy.flatten_()
         self.policy, self.optimizer, self.dist = policy, optimizer, dist
@@ -252,12 +253,19 @@ class MinibatchStep:
         self.use_graph = (dev.type == "cuda" and capturable) if use_graph is None else bool(use_graph)
         self.stats = torch.zeros(5, device=dev)          # policy loss, value loss, entropy loss, clip fraction, grad norm
         self._params = list(policy.parameters())         # in flat-buffer order (flatten_ walks parameters() the same way)
+        assert self._params[0] is policy.log_std
+        self._net_params = self._params[1:]
+        # loss + its gradient in the HIP kernels (amenv_ppo_loss_grad) on the GPU; the torch expression is the host-side statement
+        self.fused_loss = (dev.type == "cuda") if fused_loss is None else bool(fused_loss)
+        self._fused_buf = None
         self._static = None
         self._graphs = None
         self._eager_calls = 0
 
     # -- the arithmetic (shared by the eager and the captured path) --------------------------------
     def _forward_backward(self, obs, actions, old_logp, adv, ret):
+        if self.fused_loss:
+            return self._forward_backward_fused(obs, actions, old_logp, adv, ret)
         if self.normalize_advantage and adv.numel() > 1:
             adv = (adv - adv.mean()) / (adv.std() + 1e-8)
         values, logp, entropy = self.policy.evaluate_actions(obs, actions)
@@ -273,6 +281,27 @@ class MinibatchStep:
         with torch.no_grad():
             self.stats[0], self.stats[1], self.stats[2] = pl.detach(), vl.detach(), el.detach()
             self.stats[3] = ((ratio.detach() - 1.0).abs() > c).float().mean()
+
+    def _forward_backward_fused(self, obs, actions, old_logp, adv, ret):
+        """Same loss, with everything between the network outputs and the backward pass in the HIP kernels of
+        `amenv_ppo_loss_grad` (3 launches for ~60): autograd only walks the two MLPs, seeded with d L / d mean and d L / d value."""
+        pol = self.policy
+        mean, values = pol.actor(obs), pol.critic(obs)
+        n, a = mean.shape
+        if self._fused_buf is None or self._fused_buf[0].shape[0] != n:
+            f = dict(dtype=torch.float32, device=mean.device)
+            self._fused_buf = (torch.empty(n, a, **f), torch.empty(n, **f), torch.empty(a, **f),
+                               torch.empty(L.load().amenv_ppo_workspace_bytes() // 8, dtype=torch.float64, device=mean.device))
+        d_mean, d_value, d_log_std, ws = self._fused_buf
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        m, v = mean.detach().contiguous(), values.detach().contiguous()
+        rc = L.load().amenv_ppo_loss_grad(p(m), p(v), p(pol.log_std.detach()), p(actions), p(old_logp), p(adv), p(ret), n, a, self.clip_range,
+                                          self.ent_coef, self.vf_coef, 1 if self.normalize_advantage else 0, p(d_mean), p(d_value), p(d_log_std),
+                                          p(self.stats), p(ws), C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream))
+        if rc != 0:
+            raise L.AmenvError(f"amenv_ppo_loss_grad failed ({rc})")
+        grads = torch.autograd.grad([mean, values], self._net_params, grad_outputs=[d_mean, d_value])
+        torch.cat([d_log_std] + [g.reshape(-1) for g in grads], out=pol.flat_grad)     # log_std is the first parameter
 
     def _exchange(self):
         if self.dist is not None and (self.world > 1 or self.split):
