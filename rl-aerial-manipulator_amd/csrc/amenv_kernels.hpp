@@ -293,8 +293,11 @@ constexpr int kStampSlots = 8, kStampWaves = 64, kStampBase = 16;
 struct StepTail { float* terminal_obs; float* ep_return; int32_t* ep_len; unsigned long long* stats; };
 struct Head { void* blob; uint32_t tile_bytes; int32_t n; };
 
+#ifndef AMENV_STEP_WAVES_ATTR
+#define AMENV_STEP_WAVES_ATTR
+#endif
 template <typename T, int NROT, int KW, int VAR, int NJ>
-__global__ __launch_bounds__(256) void step_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+__global__ __launch_bounds__(256) AMENV_STEP_WAVES_ATTR void step_kernel(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
                                                    float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
                                                    uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C,
                                                    const ArmArg<T, NJ> AA) {
