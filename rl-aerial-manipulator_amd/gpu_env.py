@@ -91,6 +91,8 @@ class GpuWaypointEnv:
         want = tuple(lead) + (self.num_envs, self.act_dim)
         if actions.device != self.device or actions.dtype != torch.float32 or tuple(actions.shape) != want or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.float32).reshape(want).contiguous()
+        if actions.data_ptr() % 16:    # e.g. a row of a [T, N, A] tensor with odd N*A: the kernels want 16-byte aligned buffers
+            actions = actions.clone()
         return actions
 
     def reseed(self, seed):

@@ -182,3 +182,53 @@ def test_two_wave_kernel_is_bit_identical_to_one_wave_kernel(monkeypatch):
     assert torch.equal(f0, f1) and torch.equal(i0, i1) and s0 == s1 and s0["episodes"] > 20
     for (o0, w0, d0, b0), (o1, w1, d1, b1) in zip(r0, r1):
         assert torch.equal(o0, o1) and torch.equal(w0, w1) and torch.equal(d0, d1) and torch.equal(b0, b1)
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 129])
+def test_two_wave_kernel_ragged_batches(monkeypatch, n):
+    """Batches that do not fill their last tile: the two kernels still agree bit for bit and nothing is written past row n."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("AMENV_ARM_2WAVE", flag)
+        env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=2)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        acts = (torch.randn(60, n, 7, device="cuda", generator=g) * 0.3)
+        acts[..., 0] += 0.6                       # sinking: crashes and resets within the window
+        acts = acts.clamp(-1, 2)
+        for t in range(60):
+            obs, rew, done, info = env.step(acts[t])
+        f, i = env.get_state()
+        outs.append((obs.clone(), rew.clone(), f.clone(), i.clone(), env.stats()))
+        env.close()
+    a, b = outs
+    assert all(torch.equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4]
+    assert bool(torch.isfinite(a[0]).all())
+
+
+def test_arm_long_run_stays_finite():
+    """1e8 env-steps of the headline configuration with random actions: no non-finite state, every episode ends by crash, bounds or time."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    env = amd.GpuWaypointEnv(4096, vehicle="hexa_arm", seed=1)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ring = torch.randn(64, 4096, 7, device="cuda", generator=g) * 0.5
+    ring[..., 0] += 1.0
+    ring = ring.clamp(-1, 2).contiguous()
+    graph = torch.cuda.CUDAGraph()
+    for t in range(64):
+        env.step(ring[t])
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        for t in range(64):
+            env.step(ring[t])
+    for _ in range(24414 // 64):
+        graph.replay()
+    torch.cuda.synchronize()
+    s = env.stats()
+    f, _ = env.get_state()
+    assert s["nonfinite"] == 0 and bool(torch.isfinite(f).all()) and bool(torch.isfinite(env.obs).all())
+    assert s["episodes"] > 10000 and s["episodes"] == s["terminated"] + s["truncated"]
