@@ -284,6 +284,14 @@ int amenv_gae(const float* rewards, const float* values, const uint8_t* dones, c
  * act_dim (4 or 7).  z from Philox4x32-10 keyed by (seed, env_id_offset + i, draw): pass a different `draw` per call. */
 int amenv_gaussian_act(const float* mean, const float* log_std, const float* low, const float* high, float* raw, float* clipped,
                        float* logp, int64_t n_envs, int32_t act_dim, uint64_t seed, uint32_t draw, int64_t env_id_offset, void* stream);
+/* Forward pass of the reference's policy network (SB3 MlpPolicy, net_arch [128, 64, 64], tanh, separate actor / critic trunks;
+ * v2/rl_train.py:27-30) in ONE launch: mean_out [n, act_dim] = action_net(pi trunk(obs)), value_out [n] = value_net(vf trunk(obs));
+ * either output may be NULL.  flat_params = the policy's parameters in SB3 state-dict order in one contiguous fp32 buffer
+ * (log_std, mlp_extractor.policy_net.{0,2,4}.{weight,bias}, mlp_extractor.value_net.{0,2,4}.{weight,bias}, action_net, value_net:
+ * 30,537 floats for 20-D / 4-D).  (obs_dim, act_dim) in {(20,4), (26,7), (17,4)}. */
+int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, int64_t n, float* mean_out,
+                         float* value_out, void* stream);
+
 /* The part of SB3's PPO.train between the network outputs and the backward pass, fused (three launches instead of ~60 torch
  * kernels): per-minibatch advantage normalisation (mean, unbiased std, eps 1e-8), Gaussian log-prob of `actions` under
  * (mean, log_std), ratio to old_logp, clipped surrogate, value MSE, entropy bonus -- and the gradient of

@@ -15,6 +15,7 @@
 
 #include "amenv_kernels.hpp"
 #include "amenv_obsnorm.hpp"
+#include "amenv_policy.hpp"
 #include "amenv_train.hpp"
 
 using namespace amenv_dev;
@@ -693,6 +694,18 @@ int amenv_gaussian_act(const float* mean, const float* log_std, const float* low
     case 7: hipLaunchKernelGGL(gaussian_act_kernel<7>, grid, block, 0, (hipStream_t)stream, mean, log_std, low, high, raw, clipped, logp, (int64_t)n_envs, s_lo, s_hi, draw, (int64_t)env_id_offset); break;
     default: return AMENV_ERR_INVALID;   // 4 = quad/hexa, 7 = hexa + 3 joints
   }
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, int64_t n, float* mean_out,
+                         float* value_out, void* stream) {
+  if (!flat_params || !obs || n <= 0 || (!mean_out && !value_out)) return AMENV_ERR_INVALID;
+  const dim3 grid((unsigned)((n + 63) / 64), 2), block(64 * kPolWaves);
+  hipStream_t s = (hipStream_t)stream;
+  if (obs_dim == 20 && act_dim == 4) hipLaunchKernelGGL((policy_forward_kernel<20, 4>), grid, block, 0, s, flat_params, obs, (int64_t)n, mean_out, value_out);
+  else if (obs_dim == 26 && act_dim == 7) hipLaunchKernelGGL((policy_forward_kernel<26, 7>), grid, block, 0, s, flat_params, obs, (int64_t)n, mean_out, value_out);
+  else if (obs_dim == 17 && act_dim == 4) hipLaunchKernelGGL((policy_forward_kernel<17, 4>), grid, block, 0, s, flat_params, obs, (int64_t)n, mean_out, value_out);
+  else return AMENV_ERR_INVALID;   // (20,4) v2 | (26,7) hexacopter + arm | (17,4) v1
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

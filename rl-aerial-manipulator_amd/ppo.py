@@ -108,11 +108,44 @@ class ActorCritic(nn.Module):
         self.flat_param = self.flat_grad = None
 
     # ---- forward pieces -----------------------------------------------------------------------
+    _FUSED_DIMS = {(20, 4), (26, 7), (17, 4)}
+
+    def fused_ok(self, obs):
+        """The one-launch HIP forward (`amenv_policy_forward`) applies: inference on the GPU, parameters in the flat buffer,
+        the reference's architecture.  Training passes (autograd) go through the torch modules."""
+        return (self.flat_param is not None and self.flat_param.data_ptr() == self.log_std.data_ptr()   # still the parameters' home
+                and obs.is_cuda and obs.device == self.flat_param.device and not torch.is_grad_enabled() and self.net_arch == (128, 64, 64)
+                and (self.obs_dim, self.act_dim) in self._FUSED_DIMS and obs.dtype == torch.float32 and obs.dim() == 2)
+
+    def forward_fused(self, obs, want_mean=True, want_value=True):
+        """mean [n, A] and / or value [n] of a batch of observations in ONE kernel launch (weights as scalar operands of the FMAs,
+        activations through LDS; csrc/amenv_policy.hpp) instead of 14 library kernels."""
+        obs = obs.contiguous()
+        n = obs.shape[0]
+        mean = torch.empty(n, self.act_dim, dtype=torch.float32, device=obs.device) if want_mean else None
+        value = torch.empty(n, dtype=torch.float32, device=obs.device) if want_value else None
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = L.load().amenv_policy_forward(p(self.flat_param.detach()), self.obs_dim, self.act_dim, p(obs), n, p(mean), p(value),
+                                           C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        if rc != 0:
+            raise L.AmenvError(f"amenv_policy_forward failed ({rc})")
+        return mean, value
+
     def actor(self, obs):
+        if self.fused_ok(obs):
+            return self.forward_fused(obs, True, False)[0]
         return self.action_net(self.mlp_extractor.policy_net(obs))
 
     def critic(self, obs):
+        if self.fused_ok(obs):
+            return self.forward_fused(obs, False, True)[1]
         return self.value_net(self.mlp_extractor.value_net(obs)).squeeze(-1)
+
+    def actor_critic(self, obs):
+        """mean, value -- one launch on the GPU inference path."""
+        if self.fused_ok(obs):
+            return self.forward_fused(obs, True, True)
+        return self.actor(obs), self.critic(obs)
 
     def evaluate_actions(self, obs, actions):
         """values, log pi(a|s), entropy -- SB3 ActorCriticPolicy.evaluate_actions for DiagGaussianDistribution."""
@@ -125,6 +158,8 @@ class ActorCritic(nn.Module):
     @torch.no_grad()
     def predict(self, obs, deterministic=True, generator=None):
         """Action for the env: mean (or a sample) clipped to the action space, as SB3's `policy.predict`."""
+        if obs.is_cuda and (self.flat_param is None or self.flat_param.data_ptr() != self.log_std.data_ptr()):
+            self.flatten_()          # inference on the GPU goes through the one-launch forward, which reads the flat buffer
         mean = self.actor(obs)
         if not deterministic:
             mean = mean + torch.exp(self.log_std) * torch.randn(mean.shape, device=mean.device, generator=generator)
@@ -458,8 +493,9 @@ class PPO:
         gid0 = int(env.cfg.env_id_offset)
         for t in range(self.n_steps):
             obs_t = b.obs[t]
-            b.values[t].copy_(pol.critic(obs_t))
-            gaussian_act(pol.actor(obs_t), pol.log_std.data, pol.action_low, pol.action_high, b.actions[t], self._clipped, b.logp[t],
+            mean_t, value_t = pol.actor_critic(obs_t)
+            b.values[t].copy_(value_t)
+            gaussian_act(mean_t, pol.log_std.data, pol.action_low, pol.action_high, b.actions[t], self._clipped, b.logp[t],
                          self.seed, self._draw, gid0)
             self._draw += 1
             if self.obs_normalizer is None:

@@ -290,3 +290,51 @@ def test_fused_ppo_loss_kernel_matches_autograd(A, normalize):
     plain = MinibatchStep(pol, opt, normalize_advantage=normalize, use_graph=False, fused_loss=False)
     plain._forward_backward(obs, actions, old_logp, adv, ret)
     assert float((pol.flat_grad.double() - g_ref).abs().max() / scale) < 2e-5
+
+
+@pytest.mark.parametrize("D,A", [(20, 4), (26, 7), (17, 4)])
+@pytest.mark.parametrize("n", [1, 64, 1000, 32768])
+def test_fused_policy_forward_matches_torch_modules(D, A, n):
+    """amenv_policy_forward (one launch: scalar-operand weights, LDS activations) against the torch modules it replaces on the
+    inference path, for the three (obs, action) shapes of the envs."""
+    torch.manual_seed(D * 100 + A)
+    pol = ActorCritic(D, A).to("cuda").flatten_()
+    with torch.no_grad():
+        pol.flat_param.mul_(1.7)                                    # larger pre-activations: tanh away from its linear range
+        pol.action_net.weight.mul_(30.0)
+    obs = torch.randn(n, D, device="cuda") * 1.5
+    with torch.no_grad():
+        assert pol.fused_ok(obs)
+        mean, value = pol.actor_critic(obs)
+        ref_mean = pol.action_net(pol.mlp_extractor.policy_net(obs))
+        ref_value = pol.value_net(pol.mlp_extractor.value_net(obs)).squeeze(-1)
+        only_v = pol.critic(obs)
+    assert mean.shape == (n, A) and value.shape == (n,)
+    assert float((mean - ref_mean).abs().max()) < 2e-5 * max(1.0, float(ref_mean.abs().max()))
+    assert float((value - ref_value).abs().max()) < 2e-5 * max(1.0, float(ref_value.abs().max()))
+    assert torch.equal(only_v, value)
+    with torch.enable_grad():                                           # training passes stay on the torch modules
+        assert not pol.fused_ok(obs) and pol.actor(obs).requires_grad
+
+
+def test_fused_policy_forward_reproduces_recorded_actions_and_is_capturable():
+    """The reference checkpoint through the fused forward: the actions recorded from the reference (golden policy episodes), and the
+    same launch replayed from a HIP graph."""
+    import glob
+    pol = fixture_policy("cuda")
+    n = 0
+    for f in sorted(glob.glob(os.path.join(GOLD, "policy_ep*.npz"))):
+        g = np.load(f)
+        obs_seen = torch.from_numpy(np.concatenate([g["obs0"][None], g["obs"][:-1]])).cuda()
+        a = pol.predict(obs_seen)
+        assert pol.flat_param is not None and float((a.cpu() - torch.from_numpy(g["actions"])).abs().max()) < 3e-6
+        n += len(a)
+    assert n > 2000
+    obs = torch.randn(4096, 20, device="cuda")
+    out = pol.predict(obs)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out2 = pol.predict(obs)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
