@@ -190,7 +190,9 @@ def main():
                      "kernel_us_isolated": kern_ms * 1e3, "kernel_us_isolated_min": min(per),
                      "isolated_timing": f"mean of {pairs} single launches, start/stop events stamped by the kernel dispatch (amenv_step_timed), each followed by a host sync",
                      "note": f"{n} envs = {(n + 63) // 64 * (2 if 'arm2w' in env.kernel_name else 1)} wavefronts on 256 CUs, {n * bytes_step / 1e6:.2f} MB algorithmic per launch"
-                             + ("; latency-bound by construction (dependent-launch floor on this box 1.66 us, SURVEY 7.3-4)" if n <= 65536 else "")},
+                             + ("; latency-bound by construction: the launch is as long as one wave's instruction stream (one VALU instruction per 4 clocks for a lone wave; "
+                                "SQ counters in profiles/: the critical wave issues VALU ~56 % of its lifetime, the rest is load / LDS / barrier latency), "
+                                "so the HBM fraction is small by design -- DESIGN.md section 6" if n <= 65536 else "")},
         "device_ms_per_step": dev_ms / K,
         "episodes_finished_rank0": stats["episodes"],
     }
