@@ -102,6 +102,16 @@ constexpr int kArmXchgSlots = 27;   // 21 partial sums + wd(3) + vd(3), [slot][6
 struct NoXchg {};
 struct LdsXchg {
   float* base; int lane;
+#ifdef AMENV_STAMPS
+  unsigned long long* st;   // diagnostic build: accumulated durations of the main wave's RHS phases (own | bar1 | serial | bar2)
+  __device__ __forceinline__ unsigned long long now() const {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  }
+#endif
   __device__ __forceinline__ void put(int slot, float v) const { base[slot * 64 + lane] = v; }
   __device__ __forceinline__ float get(int slot) const { return base[slot * 64 + lane]; }
   // barrier fenced for the instruction scheduler on both sides: ALU work must neither sink below nor rise above it, or the two
@@ -117,6 +127,10 @@ struct LdsXchg {
 template <typename T, typename AX, typename PT, int ROLE = ARM_ROLE_ALL, typename X = NoXchg>
 __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{}) {
   static_assert(ROLE == ARM_ROLE_ALL || (AX::code[0] == 2 && AX::code[1] == 0 && sizeof(T) == 4), "two-wave roles: z,x,x arm, fp32");
+#ifdef AMENV_STAMPS
+  unsigned long long t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0;
+  if constexpr (ROLE == ARM_ROLE_MAIN) t0_ = x.now();
+#endif
   const V3<T> om{y[10], y[11], y[12]};
   // rotation of the normalised quaternion (body -> world is its transpose, as in the rigid model)
   const T n2 = fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9])));
@@ -254,7 +268,13 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
                         "+v"(IO[0]), "+v"(IO[1]), "+v"(IO[2]), "+v"(IO[3]), "+v"(IO[4]), "+v"(IO[5]));
       asm volatile("" : "+v"(Rq.m[0]), "+v"(Rq.m[1]), "+v"(Rq.m[2]), "+v"(Rq.m[3]), "+v"(Rq.m[4]), "+v"(Rq.m[5]), "+v"(Rq.m[6]),
                         "+v"(Rq.m[7]), "+v"(Rq.m[8]));
+#ifdef AMENV_STAMPS
+      t1_ = x.now();
+#endif
       x.sync();
+#ifdef AMENV_STAMPS
+      t2_ = x.now();
+#endif
       S = S + V3<T>{T(x.get(0)), T(x.get(1)), T(x.get(2))};
       fb = fb + V3<T>{T(x.get(3)), T(x.get(4)), T(x.get(5))};
       nb = nb + V3<T>{T(x.get(6)), T(x.get(7)), T(x.get(8))} + V3<T>{T(x.get(9)), T(x.get(10)), T(x.get(11))} +
@@ -281,7 +301,13 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
     if constexpr (ROLE == ARM_ROLE_MAIN) {
       x.put(21, float(wd.x)); x.put(22, float(wd.y)); x.put(23, float(wd.z));
       x.put(24, float(vd.x)); x.put(25, float(vd.y)); x.put(26, float(vd.z));
+#ifdef AMENV_STAMPS
+      t3_ = x.now();
+#endif
       x.sync();
+#ifdef AMENV_STAMPS
+      { const unsigned long long t4_ = x.now(); x.st[3] += t1_ - t0_; x.st[4] += t2_ - t1_; x.st[5] += t3_ - t2_; x.st[6] += t4_ - t3_; }
+#endif
     }
   }
   d[0] = y[3]; d[1] = y[4]; d[2] = y[5];

@@ -380,6 +380,10 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
                                                          const ArmArg<T, 3> AA) {
   constexpr int KW = 1, VAR = VAR_V2, NJ = 3;
   constexpr int OD = ObsDim<VAR, NJ>::value, AD = kActDim + NJ;
+#ifdef AMENV_STAMPS
+  unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  AMENV_STAMP(0);
   const Head hd{blob, tile_bytes, n_envs};
   const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging, then [kArmXchgSlots][64] exchange
@@ -388,13 +392,20 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
   const int i = blockIdx.x * 64 + lane;
   const bool active = i < hd.n;
   char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
+#ifdef AMENV_STAMPS
+  const LdsXchg x{lds + 64 * OD, lane, stamps_};
+#else
   const LdsXchg x{lds + 64 * OD, lane};
+#endif
   Env<T, KW> e;
   load_env<T, KW, NJ>(1, tile, lane, e);
   float act[AD];
   const float* ap = reinterpret_cast<const float*>(io.actions) + size_t(min(i, hd.n - 1)) * AD;
 #pragma unroll
   for (int j = 0; j < AD; j++) act[j] = ap[j];
+  AMENV_STAMP(1);          // loads issued
+  if (role == 0) { AMENV_STAMP_DRAIN(); }
+  AMENV_STAMP(2);          // (main) loads landed
   if (role != 0) {
     // helper: link 3's share of the RK4, then the observation of every lane (a pure function of the post-step state for the
     // single-waypoint task), staged in LDS and flushed coalesced -- all off the main wave's critical path
@@ -428,6 +439,12 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
 #pragma unroll
     for (int j = 0; j < OD; j++) d[j] = o[j];
   }
+#ifdef AMENV_STAMPS
+  AMENV_STAMP_DRAIN();
+  AMENV_STAMP(7);          // all stores acknowledged
+  if (lane == 0 && blockIdx.x < kStampWaves)
+    for (int kk = 0; kk < kStampSlots; kk++) io.stats[kStampBase + blockIdx.x * kStampSlots + kk] = stamps_[kk];
+#endif
 }
 
 // n_steps control steps per launch with open-loop actions [T][N][4]; per-step outputs [T][N]...

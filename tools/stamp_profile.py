@@ -32,6 +32,9 @@ ring[..., 4:] *= 3.0
 ring = ring.clamp(min=-1, max=2).contiguous()
 names = ["entry->loads issued", "loads issued->landed", "compute (mixer+RK4+task+obs)", "state/output stores issued", "LDS stage+barrier+obs flush",
          "stats", "drain stores (vmcnt 0)"]
+if "arm2w" in env.kernel_name:   # two-wave arm kernel: stamps of the MAIN wave of each tile
+    names = ["entry->loads issued", "loads issued->landed", "RK4 (with helper) + task step", "stats + state/output stores issued",
+             "final barrier (helper's obs rows landed)", "reset rows (rare)", "drain stores (vmcnt 0)"]
 rows, raws = [], []
 nw = min(64, (a.envs + 63) // 64)
 for t in range(a.launches):
