@@ -293,7 +293,7 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
     const V3<T> rhs = n - im * cross(S, f);
     const T c00 = fma_(dd, ff, -(e * e)), c01 = fma_(c, e, -(bq * ff)), c02 = fma_(bq, e, -(c * dd));
     const T c11 = fma_(a, ff, -(c * c)), c12 = fma_(bq, c, -(a * e)), c22 = fma_(a, dd, -(bq * bq));
-    const T idet = T(1) / fma_(a, c00, fma_(bq, c01, c * c02));
+    const T idet = rcp_(fma_(a, c00, fma_(bq, c01, c * c02)));   // v_rcp_f32 (1 ulp) for fp32: the IEEE division sequence is ~10 dependent instructions on the serial path
     wd = V3<T>{idet * dot3_(c00, c01, c02, rhs.x, rhs.y, rhs.z), idet * dot3_(c01, c11, c12, rhs.x, rhs.y, rhs.z),
                idet * dot3_(c02, c12, c22, rhs.x, rhs.y, rhs.z)};
     const V3<T> Aacc = im * (f + cross(S, wd));
