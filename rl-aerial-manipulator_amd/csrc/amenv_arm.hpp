@@ -98,7 +98,11 @@ __device__ __forceinline__ void rotate_about_column(M3<T>& R, T th) {
 // main -> helper the 6 solved accelerations.  The partials are added in the order the one-wave code adds them, so both variants
 // (and the rollout kernel) give bit-identical trajectories.
 enum { ARM_ROLE_ALL = 0, ARM_ROLE_MAIN = 1, ARM_ROLE_HELPER = 2 };
-constexpr int kArmXchgSlots = 27;   // 21 partial sums + wd(3) + vd(3), [slot][64 lanes] floats
+constexpr int kArmPreSlot = 27;     // link 2's body-frame kinematics of the NEXT stage, precomputed by the helper: r u a_ (9) J (6) w al (6)
+constexpr int kArmXchgSlots = 48;   // 21 partial sums + wd(3) + vd(3) + 21 precomputed, [slot][64 lanes] floats
+// Chain quantities behind joint 2 (rotation, position / velocity / acceleration of the joint-3 origin, angular velocity / acceleration
+// of link 2), carried by the helper wave from its look-ahead to its own share of the next RHS.
+template <typename T> struct ChainState { T R[9], v[15]; };
 struct NoXchg {};
 struct LdsXchg {
   float* base; int lane;
@@ -124,8 +128,15 @@ struct LdsXchg {
 };
 
 // 19 derivatives of the arm vehicle.  y: state, F / M: rotor wrench after the mixer, cmd: joint position commands.
-template <typename T, typename AX, typename PT, int ROLE = ARM_ROLE_ALL, typename X = NoXchg>
-__device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{}) {
+// Two-wave build only: STAGE = index of this RHS in the RK4 step.  The joint servos do not feel the base, so the joint state of
+// stage n+1 (y0 + cnext * (thd, thdd) of stage n) is known before stage n's solve: while the main wave is in its serial section the
+// helper computes the next stage's chain up to joint 2 and link 2's body-frame kinematics (r, u, a, J) and leaves them in LDS; from
+// stage 1 on the main wave only adds the terms that depend on the base's angular velocity.  Same expressions, same order: bit-identical.
+template <typename T, typename AX, typename PT, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, int STAGE = 0>
+__device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{},
+                                             const T* y0 = nullptr, T cnext = T(0), ChainState<T>* cs = nullptr) {
+  constexpr bool kPreIn = ROLE != ARM_ROLE_ALL && STAGE > 0;     // link 2 / the chain were prepared during the previous stage
+  constexpr bool kPreOut = ROLE == ARM_ROLE_HELPER && STAGE < 3;  // prepare them for the next stage
   static_assert(ROLE == ARM_ROLE_ALL || (AX::code[0] == 2 && AX::code[1] == 0 && sizeof(T) == 4), "two-wave roles: z,x,x arm, fp32");
 #ifdef AMENV_STAMPS
   unsigned long long t0_ = 0, t1_ = 0, t2_ = 0, t3_ = 0;
@@ -195,19 +206,28 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
     IO[4] += J.m[5] - m * (r.y * r.z);
     IO[5] += J.m[8] + m * (r2 - r.z * r.z);
   };
-  auto leaf = [&](auto kc) {
+  // body-frame kinematics of link k (independent of the base's motion): CoM position / velocity / acceleration, inertia J = R I R^T
+  auto leaf_indep = [&](auto kc, V3<T>& r, V3<T>& u, V3<T>& a_, T* J6) {
     constexpr int k = decltype(kc)::value;
     const V3<T> Rc = mul(R, V3<T>{A.lc[k][0], A.lc[k][1], A.lc[k][2]});
     const V3<T> wRc = cross(w, Rc);
-    const V3<T> r = p + Rc, u = pd + wRc, a_ = pdd + cross(al, Rc) + cross(w, wRc);
-    const V3<T> b = cross(om, cross(om, r)) + T(2) * cross(om, u) + a_;
-    // link inertia in body axes, once: J = R I R^T (symmetric, 6 entries); every rotational term and I_O use it
+    r = p + Rc; u = pd + wRc; a_ = pdd + cross(al, Rc) + cross(w, wRc);
     const M3<T> Ik{{A.li[k][0], A.li[k][1], A.li[k][2], A.li[k][1], A.li[k][3], A.li[k][4], A.li[k][2], A.li[k][4], A.li[k][5]}};
     const M3<T> RI = mul(R, Ik);
-    const T Jxx = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[0], R.m[1], R.m[2]), Jxy = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[3], R.m[4], R.m[5]);
-    const T Jxz = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[6], R.m[7], R.m[8]), Jyy = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[3], R.m[4], R.m[5]);
-    const T Jyz = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[6], R.m[7], R.m[8]), Jzz = dot3_(RI.m[6], RI.m[7], RI.m[8], R.m[6], R.m[7], R.m[8]);
-    accumulate(A.lm[k], r, b, M3<T>{{Jxx, Jxy, Jxz, Jxy, Jyy, Jyz, Jxz, Jyz, Jzz}}, al + cross(om, w), om + w);
+    J6[0] = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[0], R.m[1], R.m[2]); J6[1] = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[3], R.m[4], R.m[5]);
+    J6[2] = dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[6], R.m[7], R.m[8]); J6[3] = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[3], R.m[4], R.m[5]);
+    J6[4] = dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[6], R.m[7], R.m[8]); J6[5] = dot3_(RI.m[6], RI.m[7], RI.m[8], R.m[6], R.m[7], R.m[8]);
+  };
+  // the terms that involve the base's angular velocity, and the sums
+  auto leaf_dep = [&](T m, V3<T> r, V3<T> u, V3<T> a_, const T* J6, V3<T> wl, V3<T> all) {
+    const V3<T> b = cross(om, cross(om, r)) + T(2) * cross(om, u) + a_;
+    accumulate(m, r, b, M3<T>{{J6[0], J6[1], J6[2], J6[1], J6[3], J6[4], J6[2], J6[4], J6[5]}}, all + cross(om, wl), om + wl);
+  };
+  auto leaf = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    V3<T> r, u, a_; T J6[6];
+    leaf_indep(kc, r, u, a_, J6);
+    leaf_dep(A.lm[k], r, u, a_, J6, w, al);
   };
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
   if constexpr (AX::code[0] == 2 && AX::code[1] == 0) {
@@ -234,20 +254,38 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
       accumulate(A.lm[0], r, b, M3<T>{{Jxx, Jxy, q02, Jxy, Jyy, q12, q02, q12, Izz}},
                  V3<T>{om.y * wz, -(om.x * wz), az}, V3<T>{om.x, om.y, om.z + wz});
     }
-    {  // across joint 2 (axis x of the frame Rz(th1)): chain quantities at joint 2, then R = Rz(th1) Rx(th2)
+    // across joint 2 (axis x of the frame Rz(th1)): chain quantities at joint 2, then R = Rz(th1) Rx(th2)
+    auto chain_to_joint2 = [&](T s0_, T c0_, T wz_, T az_, T th1, T td, T tdd) {
       const T ox = A.jo[1][0], oy = A.jo[1][1], oz = A.jo[1][2];
-      const V3<T> Ro{fma_(c0, ox, -(s0 * oy)), fma_(s0, ox, c0 * oy), oz};
-      pd = V3<T>{-(wz * Ro.y), wz * Ro.x, T(0)};                                        // w x Ro
-      pdd = V3<T>{fma_(-az, Ro.y, -(wz * pd.y)), fma_(az, Ro.x, wz * pd.x), T(0)};
+      const V3<T> Ro{fma_(c0_, ox, -(s0_ * oy)), fma_(s0_, ox, c0_ * oy), oz};
+      pd = V3<T>{-(wz_ * Ro.y), wz_ * Ro.x, T(0)};                                        // w x Ro
+      pdd = V3<T>{fma_(-az_, Ro.y, -(wz_ * pd.y)), fma_(az_, Ro.x, wz_ * pd.x), T(0)};
       p = o0 + Ro;
-      const T td = y[17], tdd = thdd[1];
-      al = V3<T>{fma_(tdd, c0, -(td * (wz * s0))), fma_(tdd, s0, td * (wz * c0)), az};   // + thdd z + thd (w x z), z = (c0, s0, 0)
-      w = V3<T>{td * c0, td * s0, wz};
+      al = V3<T>{fma_(tdd, c0_, -(td * (wz_ * s0_))), fma_(tdd, s0_, td * (wz_ * c0_)), az_};   // + thdd z + thd (w x z), z = (c0, s0, 0)
+      w = V3<T>{td * c0_, td * s0_, wz_};
       T s1, c1;
-      sincos_(y[14], s1, c1);
-      R = M3<T>{{c0, -(c1 * s0), s1 * s0, s0, c1 * c0, -(s1 * c0), T(0), s1, c1}};
+      sincos_(th1, s1, c1);
+      R = M3<T>{{c0_, -(c1 * s0_), s1 * s0_, s0_, c1 * c0_, -(s1 * c0_), T(0), s1, c1}};
+    };
+    if constexpr (!kPreIn) {
+      chain_to_joint2(s0, c0, wz, az, y[14], y[17], thdd[1]);
+    } else if constexpr (ROLE == ARM_ROLE_HELPER) {   // carried over from this wave's look-ahead during the previous stage
+#pragma unroll
+      for (int q = 0; q < 9; q++) R.m[q] = cs->R[q];
+      p = V3<T>{cs->v[0], cs->v[1], cs->v[2]}; pd = V3<T>{cs->v[3], cs->v[4], cs->v[5]}; pdd = V3<T>{cs->v[6], cs->v[7], cs->v[8]};
+      w = V3<T>{cs->v[9], cs->v[10], cs->v[11]}; al = V3<T>{cs->v[12], cs->v[13], cs->v[14]};
     }
-    if constexpr (ROLE != ARM_ROLE_HELPER) leaf(K1{});
+    if constexpr (ROLE != ARM_ROLE_HELPER) {
+      if constexpr (kPreIn) {                         // link 2's body-frame kinematics came from the helper
+        T g[21];
+#pragma unroll
+        for (int q = 0; q < 21; q++) g[q] = T(x.get(kArmPreSlot + q));
+        leaf_dep(A.lm[1], V3<T>{g[0], g[1], g[2]}, V3<T>{g[3], g[4], g[5]}, V3<T>{g[6], g[7], g[8]}, &g[9], V3<T>{g[15], g[16], g[17]},
+                 V3<T>{g[18], g[19], g[20]});
+      } else {
+        leaf(K1{});
+      }
+    }
     if constexpr (ROLE != ARM_ROLE_MAIN) { advance(K2{}); leaf(K2{}); }
   } else {
     advance(K0{}); leaf(K0{});
@@ -257,6 +295,43 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   V3<T> wd, vd;
   if constexpr (ROLE == ARM_ROLE_HELPER) {
     x.sync();                                     // partial sums are in LDS
+    if constexpr (kPreOut) {                      // look-ahead while the main wave solves: joint state, chain and link 2 of the next stage
+      if constexpr (AX::code[0] == 2 && AX::code[1] == 0) {
+        T thn[3], tdn[3], tddn[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          thn[k] = fma_(cnext, y[16 + k], y0[13 + k]);          // = the next stage's s[13+k], s[16+k] as dynamics_arm forms them
+          tdn[k] = fma_(cnext, thdd[k], y0[16 + k]);
+          tddn[k] = clamp_(fma_(A.kp, cmd[k] - thn[k], -(A.kd * tdn[k])), -A.amax, A.amax);
+        }
+        T s0n, c0n;
+        sincos_(thn[0], s0n, c0n);
+        const V3<T> o0{A.jo[0][0], A.jo[0][1], A.jo[0][2]};
+        {
+          const T ox = A.jo[1][0], oy = A.jo[1][1], oz = A.jo[1][2];
+          const V3<T> Ro{fma_(c0n, ox, -(s0n * oy)), fma_(s0n, ox, c0n * oy), oz};
+          const T wz_ = tdn[0], az_ = tddn[0], td = tdn[1], tdd = tddn[1];
+          pd = V3<T>{-(wz_ * Ro.y), wz_ * Ro.x, T(0)};
+          pdd = V3<T>{fma_(-az_, Ro.y, -(wz_ * pd.y)), fma_(az_, Ro.x, wz_ * pd.x), T(0)};
+          p = o0 + Ro;
+          al = V3<T>{fma_(tdd, c0n, -(td * (wz_ * s0n))), fma_(tdd, s0n, td * (wz_ * c0n)), az_};
+          w = V3<T>{td * c0n, td * s0n, wz_};
+          T s1, c1;
+          sincos_(thn[1], s1, c1);
+          R = M3<T>{{c0n, -(c1 * s0n), s1 * s0n, s0n, c1 * c0n, -(s1 * c0n), T(0), s1, c1}};
+        }
+        V3<T> r2, u2, a2; T J6[6];
+        leaf_indep(K1{}, r2, u2, a2, J6);
+        const T g[21] = {r2.x, r2.y, r2.z, u2.x, u2.y, u2.z, a2.x, a2.y, a2.z, J6[0], J6[1], J6[2], J6[3], J6[4], J6[5], w.x, w.y, w.z, al.x, al.y, al.z};
+#pragma unroll
+        for (int q = 0; q < 21; q++) x.put(kArmPreSlot + q, float(g[q]));
+#pragma unroll
+        for (int q = 0; q < 9; q++) cs->R[q] = R.m[q];
+        const T cv[15] = {p.x, p.y, p.z, pd.x, pd.y, pd.z, pdd.x, pdd.y, pdd.z, w.x, w.y, w.z, al.x, al.y, al.z};
+#pragma unroll
+        for (int q = 0; q < 15; q++) cs->v[q] = cv[q];
+      }
+    }
     x.sync();                                     // the main wave has solved
     wd = V3<T>{T(x.get(21)), T(x.get(22)), T(x.get(23))};
     vd = V3<T>{T(x.get(24)), T(x.get(25)), T(x.get(26))};
@@ -322,9 +397,10 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   for (int k = 0; k < 3; k++) { d[13 + k] = y[16 + k]; d[16 + k] = thdd[k]; }
 }
 
-template <typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, typename T, typename PT>
-__device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{}) {
-  arm_rhs_body<T, AX, PT, ROLE, X>(P, A, y, F, M, cmd, d, x);
+template <typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, int STAGE = 0, typename T, typename PT>
+__device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{},
+                                        const T* y0 = nullptr, T cnext = T(0), ChainState<T>* cs = nullptr) {
+  arm_rhs_body<T, AX, PT, ROLE, X, STAGE>(P, A, y, F, M, cmd, d, x, y0, cnext, cs);
 }
 
 // One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states.
@@ -351,16 +427,17 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
     // RK4 with a running weighted sum (acc = k1 + 2 k2 + 2 k3 + k4): four 19-vectors live instead of six -- the fp64
     // build of this kernel otherwise needs more than the 512 registers a wave can have
     T k[19], acc[19], s[19];
-    arm_rhs<AX, ROLE, X>(P, A, y, F, M, cmd, k, x);
+    [[maybe_unused]] ChainState<T> cs;   // helper wave: chain behind joint 2, from its look-ahead to the next RHS
+    arm_rhs<AX, ROLE, X, 0>(P, A, y, F, M, cmd, k, x, y, hh, &cs);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = k[i]; s[i] = fma_(hh, k[i], y[i]); }
-    arm_rhs<AX, ROLE, X>(P, A, s, F, M, cmd, k, x);
+    arm_rhs<AX, ROLE, X, 1>(P, A, s, F, M, cmd, k, x, y, hh, &cs);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(hh, k[i], y[i]); }
-    arm_rhs<AX, ROLE, X>(P, A, s, F, M, cmd, k, x);
+    arm_rhs<AX, ROLE, X, 2>(P, A, s, F, M, cmd, k, x, y, h, &cs);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(h, k[i], y[i]); }
-    arm_rhs<AX, ROLE, X>(P, A, s, F, M, cmd, k, x);
+    arm_rhs<AX, ROLE, X, 3>(P, A, s, F, M, cmd, k, x, y, T(0), &cs);
 #pragma unroll
     for (int i = 0; i < 19; i++) y[i] = fma_(h6, acc[i] + k[i], y[i]);
   } while (++it < P.substeps);
