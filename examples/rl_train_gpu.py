@@ -6,6 +6,10 @@
 Same hyper-parameters as the reference (lr 2e-4, 12 epochs, gamma .995, lambda .9, clip .2, ent 5e-4 -- 1e-4 when resuming,
 :35 -- MLP [128,64,64] tanh); the rollout is `envs x n_steps` instead of `8 x 2048`, so n_steps / batch_size are rescaled to
 keep the reference's 16,384-sample rollouts x 128-sample minibatches ratio (128 minibatches per epoch).
+
+Defaults = the run recorded in profiles/r01/ppo_from_scratch.json: 256 envs x 512 steps, 90 M steps, ~10 minutes on one MI355X, > 90 % of
+episodes successful after 39 M steps.  Learning progress follows the number of Adam updates (1536 per iteration here), not the number of samples:
+thousands of envs with proportionally larger minibatches collect samples faster but learn no sooner.
 """
 import argparse
 import os
@@ -16,9 +20,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--n-steps", type=int, default=128)
-    ap.add_argument("--timesteps", type=int, default=4_100_000)          # rl_train.py:56
+    ap.add_argument("--envs", type=int, default=256)
+    ap.add_argument("--n-steps", type=int, default=512)
+    ap.add_argument("--timesteps", type=int, default=90_000_000)         # rl_train.py:56 uses 4.1 M per run, ~15 M in total
     ap.add_argument("--resume", default=None, help="SB3 zip / policy.pth to start from (rl_train.py:33-35)")
     ap.add_argument("--save", default="waypoint_controller_gpu")         # rl_train.py:57
     ap.add_argument("--vehicle", default="quad")

@@ -338,3 +338,17 @@ def test_fused_policy_forward_reproduces_recorded_actions_and_is_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+def test_training_script_runs(tmp_path):
+    """examples/rl_train_gpu.py (the reference's rl_train.py on the GPU stack) end to end for two small iterations: trains, saves
+    a checkpoint whose policy.pth has SB3's layout, evaluates."""
+    import subprocess
+    import sys
+    out = os.path.join(tmp_path, "model")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "rl_train_gpu.py"), "--envs", "128", "--n-steps", "64", "--timesteps", "16384",
+                        "--save", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Mean reward:" in r.stdout and os.path.exists(out + ".zip")
+    pol = ActorCritic.from_sb3(out + ".zip")
+    assert pol.num_parameters() == 30537
