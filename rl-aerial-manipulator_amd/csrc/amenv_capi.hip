@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "amenv_kernels.hpp"
 #include "amenv_obsnorm.hpp"
@@ -573,10 +574,15 @@ int amenv_stats_read(amenv* e, amenv_stats* out, int reset, void* stream) {
   if (!e || !out) return fail(e, AMENV_ERR_INVALID, "amenv_stats_read: NULL argument");
   DeviceGuard g(e->device);
   hipStream_t s = (hipStream_t)stream;
-  unsigned long long h[S_COUNT];
-  AMENV_HIP(e, hipMemcpyAsync(h, e->stats, sizeof(h), hipMemcpyDeviceToHost, s));
-  if (reset) AMENV_HIP(e, hipMemsetAsync(e->stats, 0, sizeof(h), s));
+  // the totals live in kStatsReplicas copies (contention-free atomics, amenv_kernels.hpp): one copy of all of them, summed here
+  static_assert(S_COUNT <= kStatsStride, "stats replica stride");
+  std::vector<unsigned long long> rep(size_t(kStatsReplicas) * kStatsStride);
+  AMENV_HIP(e, hipMemcpyAsync(rep.data(), e->stats, rep.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  if (reset) AMENV_HIP(e, hipMemsetAsync(e->stats, 0, rep.size() * sizeof(unsigned long long), s));
   AMENV_HIP(e, hipStreamSynchronize(s));
+  unsigned long long h[S_COUNT] = {0};
+  for (int r = 0; r < kStatsReplicas; r++)
+    for (int k = 0; k < S_COUNT; k++) h[k] += rep[size_t(r) * kStatsStride + k];
   out->steps = e->steps;
   out->episodes = h[S_EPISODES]; out->terminated = h[S_TERMINATED]; out->truncated = h[S_TRUNCATED];
   out->success = h[S_SUCCESS]; out->crashed = h[S_CRASHED]; out->oob = h[S_OOB]; out->nonfinite = h[S_NONFINITE];

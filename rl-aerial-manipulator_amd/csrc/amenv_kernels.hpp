@@ -19,6 +19,10 @@
 
 namespace amenv_dev {
 
+// Monitor totals are kept in kStatsReplicas copies (one 128-byte line each, chosen by wave index) and summed by amenv_stats_read: with one
+// copy, the ~10 atomics of every wave that finished an episode hit the same addresses and serialise in L2 -- negligible for 64 waves,
+// 45 % of the launch at 1 M envs (81.8 -> 45.4 us).
+constexpr int kStatsReplicas = 1024, kStatsStride = 16;
 enum StatSlot { S_EPISODES = 0, S_TERMINATED, S_TRUNCATED, S_SUCCESS, S_CRASHED, S_OOB, S_NONFINITE, S_LENGTH, S_RETURN_Q10, S_COUNT };
 
 constexpr uint32_t kIntBytes = 64 * 4 * sizeof(int32_t);  // 1024: one int4 per lane
@@ -147,8 +151,11 @@ __device__ __forceinline__ void flush_obs(const float* lds, float* __restrict__ 
 // ballot + popcount for the counters, a SCALAR loop over the finished lanes (v_readlane) for the length /
 // return sums -- no cross-lane shuffles -- and one no-return atomic per wave and non-zero counter.
 // Called right after the state machine so the atomics drain while the wave stores its outputs.
-__device__ __forceinline__ void accumulate_stats(unsigned long long* __restrict__ stats, uint32_t bits, bool is_done, int ep_len,
+__device__ __forceinline__ void accumulate_stats(unsigned long long* __restrict__ stats_base, int wave_index, uint32_t bits, bool is_done, int ep_len,
                                                  float ep_ret) {
+#ifdef AMENV_DIAG_NO_STATS
+  return;
+#endif
   unsigned long long m_done = __ballot(is_done);
   if (m_done == 0ull) return;  // wave-uniform
   const unsigned long long m_term = __ballot(is_done && (bits & AMENV_INFO_TERMINATED));
@@ -168,6 +175,7 @@ __device__ __forceinline__ void accumulate_stats(unsigned long long* __restrict_
     ret_sum += __builtin_isfinite(r) ? (long long)__builtin_rintf(r * 1024.0f) : 0ll;
   }
   if ((threadIdx.x & 63) == 0) {
+    unsigned long long* stats = stats_base + size_t(wave_index & (kStatsReplicas - 1)) * kStatsStride;
     atomicAdd(&stats[S_EPISODES], (unsigned long long)n_done);
     if (m_term) atomicAdd(&stats[S_TERMINATED], (unsigned long long)__popcll(m_term));
     if (m_trunc) atomicAdd(&stats[S_TRUNCATED], (unsigned long long)__popcll(m_trunc));
@@ -288,7 +296,7 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
 #define AMENV_STAMP(k)
 #define AMENV_STAMP_DRAIN()
 #endif
-constexpr int kStampSlots = 8, kStampWaves = 64, kStampBase = 16;
+constexpr int kStampSlots = 8, kStampWaves = 64, kStampBase = kStatsReplicas * kStatsStride;
 
 struct StepTail { float* terminal_obs; float* ep_return; int32_t* ep_len; unsigned long long* stats; };
 struct Head { void* blob; uint32_t tile_bytes; int32_t n; };
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) AMENV_STEP_WAVES_ATTR void step_kernel(void* _
   uint32_t bits = step_lane<T, NROT, KW, VAR, NJ>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len, ep_ret);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   AMENV_STAMP(3);          // dynamics + task + obs computed
-  accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
+  accumulate_stats(io.stats, int((blockIdx.x * blockDim.x + threadIdx.x) >> 6), bits, is_done, ep_len, ep_ret);
   store_env_step<T, KW>(tile, lane, e);
   if (NJ > 0 || was_reset) store_env_episode<T, KW, NJ>(K, tile, lane, e);
   if (active) {
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
   uint32_t bits = step_lane<T, NROT, KW, VAR, NJ, ARM_ROLE_MAIN, LdsXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset,
                                                                         ep_len, ep_ret, x);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
-  accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
+  accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
   store_env_step<T, KW>(tile, lane, e);
   store_env_episode<T, KW, NJ>(1, tile, lane, e);
   if (active) {
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
     uint32_t bits = step_lane<T, NROT, KW, VAR, NJ>(P, C, AA, e, act, i, active, reward, o, io_t, tile, lane, any_reset, was_reset, ep_len, ep_ret);
     any_reset |= was_reset;
     const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
-    accumulate_stats(io.stats, bits, is_done, ep_len, ep_ret);
+    accumulate_stats(io.stats, int((blockIdx.x * blockDim.x + threadIdx.x) >> 6), bits, is_done, ep_len, ep_ret);
     if (active) {
       if (io.reward) reinterpret_cast<T*>(io.reward)[size_t(t) * n + i] = reward;
       if (io.done) io.done[size_t(t) * n + i] = is_done ? 1 : 0;
