@@ -248,10 +248,9 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
     uint32_t r[12];
     reset_words_wave(C, resets, C.gid0 + i, e.episode, r);  // all lanes take part, lanes 0..2 do the work
     if (ended) {  // SB3 DummyVecEnv + Monitor contract
-      if constexpr (kLazyObs) obs_now();
       ep_len_out = e.step; ep_ret_out = float(e.ep_return);
       if (active) {
-        if (io.terminal_obs) {
+        if (!kLazyObs && io.terminal_obs) {   // two-wave kernel: the terminal observation is the row the helper wave staged; copied after the barrier
           float* t = io.terminal_obs + size_t(i) * OD;
           if constexpr (OD % 4 == 0) {
 #pragma unroll
@@ -442,6 +441,11 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
     io.info[i] = bits;
   }
   __syncthreads();     // the helper's observation rows have landed
+  if (is_done && io.terminal_obs) {   // SB3 terminal_observation = the pre-reset observation = the row the helper staged in LDS for this lane
+    float* t = io.terminal_obs + size_t(i) * OD;
+#pragma unroll
+    for (int j = 0; j < OD; j++) t[j] = lds[lane * OD + j];
+  }
   if (was_reset && active) {   // rare: this lane's env was auto-reset -> its row must hold the post-reset observation
     float* d = io.obs + size_t(i) * OD;
 #pragma unroll

@@ -174,14 +174,19 @@ def test_two_wave_kernel_is_bit_identical_to_one_wave_kernel(monkeypatch):
         rec = []
         for t in range(400):
             obs, rew, done, info = env.step(acts[t])
-            rec.append((obs.clone(), rew.clone(), done.clone(), info.clone()))
+            d = done.bool()
+            rec.append((obs.clone(), rew.clone(), done.clone(), info.clone(), env.terminal_obs[d].clone(), env.ep_return[d].clone(), env.ep_len[d].clone()))
         f, i = env.get_state()
         outs.append((rec, f.clone(), i.clone(), env.stats()))
         env.close()
     (r0, f0, i0, s0), (r1, f1, i1, s1) = outs
     assert torch.equal(f0, f1) and torch.equal(i0, i1) and s0 == s1 and s0["episodes"] > 20
-    for (o0, w0, d0, b0), (o1, w1, d1, b1) in zip(r0, r1):
+    n_term = 0
+    for (o0, w0, d0, b0, t0, er0, el0), (o1, w1, d1, b1, t1, er1, el1) in zip(r0, r1):
         assert torch.equal(o0, o1) and torch.equal(w0, w1) and torch.equal(d0, d1) and torch.equal(b0, b1)
+        assert torch.equal(t0, t1) and torch.equal(er0, er1) and torch.equal(el0, el1)      # SB3 terminal_observation / Monitor values
+        n_term += len(t0)
+    assert n_term > 20
 
 
 @pytest.mark.parametrize("n", [1, 63, 65, 129])
