@@ -287,7 +287,7 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   if constexpr (NJ == 3 && sizeof(T) == 4) {
     if (T_steps == 0 && e.arm2w) {   // one tile per 128-thread workgroup: main + helper wave
       const dim3 g2(e.n_tiles), b2(128);
-      const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + kArmXchgSlots * 64) * sizeof(float);
+      const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + (kArmXchgSlots + 12) * 64) * sizeof(float);   // obs rows | RK4 exchange | reset words
       if (timed) hipExtLaunchKernelGGL((step_kernel_arm2w<T, NROT>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
                                        io.done, io.info, tl, P, C, AA);
       else hipLaunchKernelGGL((step_kernel_arm2w<T, NROT>), g2, b2, lds2, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C, AA);

@@ -244,9 +244,16 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   ep_len_out = 0; ep_ret_out = 0.0f;
   const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   const bool resets = ended && (P.flags & AMENV_FLAG_AUTO_RESET);
+  if constexpr (ROLE == ARM_ROLE_MAIN) x.sync();   // two-wave kernel: the helper has left every lane's 12 reset words in LDS (every step: unconditional barrier)
   if (__ballot(ended) != 0ull) {  // wave-uniform: the whole cold path is skipped by waves with no episode end
     uint32_t r[12];
-    reset_words_wave(C, resets, C.gid0 + i, e.episode, r);  // all lanes take part, lanes 0..2 do the work
+    if constexpr (ROLE == ARM_ROLE_MAIN) {
+      const uint32_t* wl = reinterpret_cast<const uint32_t*>(x.base) + kArmXchgSlots * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 12; k++) r[k] = wl[k * 64];
+    } else {
+      reset_words_wave(C, resets, C.gid0 + i, e.episode, r);  // all lanes take part, lanes 0..2 do the work
+    }
     if (ended) {  // SB3 DummyVecEnv + Monitor contract
       ep_len_out = e.step; ep_ret_out = float(e.ep_return);
       if (active) {
@@ -417,6 +424,15 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
     // helper: link 3's share of the RK4, then the observation of every lane (a pure function of the post-step state for the
     // single-waypoint task), staged in LDS and flushed coalesced -- all off the main wave's critical path
     dynamics_arm<T, NROT, KW, AxesZXX, ARM_ROLE_HELPER, LdsXchg>(P, AA.p, e, act, x);
+    {  // the 12 Philox words a reset of this lane's env would consume (key: seed, global env id, episode): computed here, on the helper's
+       // idle time, for EVERY lane -- the main wave then never runs Philox on its cold path
+      uint32_t r[12];
+      reset_words_serial(C, C.gid0 + i, e.episode, r);
+      uint32_t* wl = reinterpret_cast<uint32_t*>(lds + 64 * OD) + kArmXchgSlots * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 12; k++) wl[k * 64] = r[k];
+      x.sync();
+    }
     float ho[kObsDimMax];
     observe<T, KW>(1, e, ho);
     observe_joints<T, KW>(e, ho);
