@@ -104,6 +104,7 @@ constexpr int kArmXchgSlots = 48;   // 21 partial sums + wd(3) + vd(3) + 21 prec
 // of link 2), carried by the helper wave from its look-ahead to its own share of the next RHS.
 template <typename T> struct ChainState { T R[9], v[15]; };
 struct NoXchg {};
+struct NoIdle { __device__ __forceinline__ void operator()(int) const {} };   // helper-wave filler work: nothing
 struct LdsXchg {
   float* base; int lane;
 #ifdef AMENV_STAMPS
@@ -132,9 +133,9 @@ struct LdsXchg {
 // stage n+1 (y0 + cnext * (thd, thdd) of stage n) is known before stage n's solve: while the main wave is in its serial section the
 // helper computes the next stage's chain up to joint 2 and link 2's body-frame kinematics (r, u, a, J) and leaves them in LDS; from
 // stage 1 on the main wave only adds the terms that depend on the base's angular velocity.  Same expressions, same order: bit-identical.
-template <typename T, typename AX, typename PT, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, int STAGE = 0>
+template <typename T, typename AX, typename PT, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, int STAGE = 0, typename IW = NoIdle>
 __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{},
-                                             const T* y0 = nullptr, T cnext = T(0), ChainState<T>* cs = nullptr) {
+                                             const T* y0 = nullptr, T cnext = T(0), ChainState<T>* cs = nullptr, const IW& idle = IW{}) {
   constexpr bool kPreIn = ROLE != ARM_ROLE_ALL && STAGE > 0;     // link 2 / the chain were prepared during the previous stage
   constexpr bool kPreOut = ROLE == ARM_ROLE_HELPER && STAGE < 3;  // prepare them for the next stage
   static_assert(ROLE == ARM_ROLE_ALL || (AX::code[0] == 2 && AX::code[1] == 0 && sizeof(T) == 4), "two-wave roles: z,x,x arm, fp32");
@@ -294,7 +295,12 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   }
   V3<T> wd, vd;
   if constexpr (ROLE == ARM_ROLE_HELPER) {
+    // filler work for the helper's idle windows (the kernel passes the Philox blocks of the reset words): part 0 where it arrives early
+    // at the first barrier of the step (its share of stage 0 is shorter than the main wave's), part 1 while the main wave does the last
+    // solve of the step (no look-ahead there)
+    if constexpr (STAGE == 0) idle(0);
     x.sync();                                     // partial sums are in LDS
+    if constexpr (STAGE == 3) idle(1);
     if constexpr (kPreOut) {                      // look-ahead while the main wave solves: joint state, chain and link 2 of the next stage
       if constexpr (AX::code[0] == 2 && AX::code[1] == 0) {
         T thn[3], tdn[3], tddn[3];
@@ -397,15 +403,16 @@ __device__ __forceinline__ void arm_rhs_body(const PT& P, const ArmParams<T>& A,
   for (int k = 0; k < 3; k++) { d[13 + k] = y[16 + k]; d[16 + k] = thdd[k]; }
 }
 
-template <typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, int STAGE = 0, typename T, typename PT>
+template <typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, int STAGE = 0, typename IW = NoIdle, typename T, typename PT>
 __device__ __forceinline__ void arm_rhs(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* cmd, T* d, const X& x = X{},
-                                        const T* y0 = nullptr, T cnext = T(0), ChainState<T>* cs = nullptr) {
-  arm_rhs_body<T, AX, PT, ROLE, X, STAGE>(P, A, y, F, M, cmd, d, x, y0, cnext, cs);
+                                        const T* y0 = nullptr, T cnext = T(0), ChainState<T>* cs = nullptr, const IW& idle = IW{}) {
+  arm_rhs_body<T, AX, PT, ROLE, X, STAGE, IW>(P, A, y, F, M, cmd, d, x, y0, cnext, cs, idle);
 }
 
 // One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states.
-template <typename T, int NROT, int KW, typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg>
-__device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act, const X& x = X{}) {
+template <typename T, int NROT, int KW, typename AX, int ROLE = ARM_ROLE_ALL, typename X = NoXchg, typename IW = NoIdle>
+__device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act, const X& x = X{},
+                                             const IW& idle = IW{}) {
   const float Ff = (act[0] * P.mass_f) * P.g_f;
   const T u0 = T(Ff), u1 = T(act[1] * P.mscale_f), u2 = T(act[2] * P.mscale_f), u3 = T(act[3] * P.mscale_f);
   T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
@@ -428,7 +435,7 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
     // build of this kernel otherwise needs more than the 512 registers a wave can have
     T k[19], acc[19], s[19];
     [[maybe_unused]] ChainState<T> cs;   // helper wave: chain behind joint 2, from its look-ahead to the next RHS
-    arm_rhs<AX, ROLE, X, 0>(P, A, y, F, M, cmd, k, x, y, hh, &cs);
+    arm_rhs<AX, ROLE, X, 0, IW>(P, A, y, F, M, cmd, k, x, y, hh, &cs, idle);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = k[i]; s[i] = fma_(hh, k[i], y[i]); }
     arm_rhs<AX, ROLE, X, 1>(P, A, s, F, M, cmd, k, x, y, hh, &cs);
@@ -437,7 +444,7 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
     arm_rhs<AX, ROLE, X, 2>(P, A, s, F, M, cmd, k, x, y, h, &cs);
 #pragma unroll
     for (int i = 0; i < 19; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(h, k[i], y[i]); }
-    arm_rhs<AX, ROLE, X, 3>(P, A, s, F, M, cmd, k, x, y, T(0), &cs);
+    arm_rhs<AX, ROLE, X, 3, IW>(P, A, s, F, M, cmd, k, x, y, T(0), &cs, idle);
 #pragma unroll
     for (int i = 0; i < 19; i++) y[i] = fma_(h6, acc[i] + k[i], y[i]);
   } while (++it < P.substeps);

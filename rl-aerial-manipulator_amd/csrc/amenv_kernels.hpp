@@ -423,14 +423,22 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
   if (role != 0) {
     // helper: link 3's share of the RK4, then the observation of every lane (a pure function of the post-step state for the
     // single-waypoint task), staged in LDS and flushed coalesced -- all off the main wave's critical path
-    dynamics_arm<T, NROT, KW, AxesZXX, ARM_ROLE_HELPER, LdsXchg>(P, AA.p, e, act, x);
-    {  // the 12 Philox words a reset of this lane's env would consume (key: seed, global env id, episode): computed here, on the helper's
-       // idle time, for EVERY lane -- the main wave then never runs Philox on its cold path
-      uint32_t r[12];
-      reset_words_serial(C, C.gid0 + i, e.episode, r);
+    // The 12 Philox words a reset of this lane's env would consume (key: seed, global env id, episode) are known from the start of the
+    // launch: the helper computes them for EVERY lane in its idle windows inside the RK4 (block 0 before the first barrier of the step,
+    // blocks 1-2 during the main wave's last solve), so the main wave never runs Philox on its cold path.
+    uint32_t rw[12];
+    const int64_t gid = C.gid0 + i;
+    const int32_t ep = e.episode;
+    auto philox_blocks = [&](int part) {
+      const uint32_t g_lo = uint32_t(uint64_t(gid)), g_hi = uint32_t(uint64_t(gid) >> 32);
+      if (part == 0) philox4x32_10(C.seed_lo, C.seed_hi, g_lo, g_hi, uint32_t(ep), 0u, &rw[0]);
+      else { philox4x32_10(C.seed_lo, C.seed_hi, g_lo, g_hi, uint32_t(ep), 1u, &rw[4]); philox4x32_10(C.seed_lo, C.seed_hi, g_lo, g_hi, uint32_t(ep), 2u, &rw[8]); }
+    };
+    dynamics_arm<T, NROT, KW, AxesZXX, ARM_ROLE_HELPER, LdsXchg>(P, AA.p, e, act, x, philox_blocks);
+    {
       uint32_t* wl = reinterpret_cast<uint32_t*>(lds + 64 * OD) + kArmXchgSlots * 64 + lane;
 #pragma unroll
-      for (int k = 0; k < 12; k++) wl[k * 64] = r[k];
+      for (int k = 0; k < 12; k++) wl[k * 64] = rw[k];
       x.sync();
     }
     float ho[kObsDimMax];
