@@ -97,7 +97,7 @@ __device__ __forceinline__ void rotate_about_column(M3<T>& R, T th) {
 // terms), the main wave the base, links 1-2, the 3x3 solve.  They meet twice per RHS through LDS: helper -> main 21 partial sums,
 // main -> helper the 6 solved accelerations.  The partials are added in the order the one-wave code adds them, so both variants
 // (and the rollout kernel) give bit-identical trajectories.
-enum { ARM_ROLE_ALL = 0, ARM_ROLE_MAIN = 1, ARM_ROLE_HELPER = 2 };
+enum { ARM_ROLE_ALL = 0, ARM_ROLE_MAIN = 1, ARM_ROLE_HELPER = 2, ARM_ROLE_WORDS = 3 };   // WORDS: rigid kernels whose reset words come from a helper wave
 constexpr int kArmPreSlot = 27;     // link 2's body-frame kinematics of the NEXT stage, precomputed by the helper: r u a_ (9) J (6) w al (6)
 constexpr int kArmXchgSlots = 48;   // 21 partial sums + wd(3) + vd(3) + 21 precomputed, [slot][64 lanes] floats
 // Chain quantities behind joint 2 (rotation, position / velocity / acceleration of the joint-3 origin, angular velocity / acceleration
@@ -107,6 +107,7 @@ struct NoXchg {};
 struct NoIdle { __device__ __forceinline__ void operator()(int) const {} };   // helper-wave filler work: nothing
 struct LdsXchg {
   float* base; int lane;
+  const uint32_t* words;   // [12][64] reset words of the tile's lanes, written by the helper wave
 #ifdef AMENV_STAMPS
   unsigned long long* st;   // diagnostic build: accumulated durations of the main wave's RHS phases (own | bar1 | serial | bar2)
   __device__ __forceinline__ unsigned long long now() const {

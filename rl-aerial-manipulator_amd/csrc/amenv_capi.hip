@@ -32,6 +32,7 @@ struct amenv {
   int n_tiles = 0;
   int block = 64;
   bool arm2w = false;              // hexacopter + z,x,x arm at small batches: two-wave step kernel (amenv_kernels.hpp)
+  bool pwave = false;              // rigid vehicles at small batches: second wave per tile computes the reset RNG words (step_kernel_pw)
   uint64_t steps = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // amenv_step_timed only
   std::string err;
@@ -294,6 +295,16 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
       return hipGetLastError();
     }
   }
+  if constexpr (NJ == 0) {
+    if (T_steps == 0 && e.pwave) {   // one tile per 128-thread workgroup: main wave + reset-RNG wave
+      const dim3 g2(e.n_tiles), b2(128);
+      const size_t lds2 = size_t(64 * ObsDim<VAR, 0>::value + 12 * 64) * sizeof(float);
+      if (timed) hipExtLaunchKernelGGL((step_kernel_pw<T, NROT, KW, VAR>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
+                                       io.done, io.info, tl, P, C);
+      else hipLaunchKernelGGL((step_kernel_pw<T, NROT, KW, VAR>), g2, b2, lds2, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C);
+      return hipGetLastError();
+    }
+  }
   if (T_steps > 0) {
     hipLaunchKernelGGL((rollout_kernel<T, NROT, KW, VAR, NJ>), grid, block, lds, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, T_steps, tl, P, C, AA);
   } else if (timed) {  // same kernel, launched with dispatch-stamped start/stop events
@@ -449,8 +460,17 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     const char* ov = std::getenv("AMENV_ARM_2WAVE");
     e->arm2w = !ap.generic_axes && (ov ? ov[0] == '1' : cfg->num_envs <= 65536);
   }
-  char buf[160];
-  if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
+  if (cfg->vehicle.n_joints == 0 && cfg->block_size == 0) {
+    // rigid vehicles: a reset-RNG helper wave per tile while the launch is latency-bound; AMENV_PHILOX_WAVE=0/1 overrides
+    const char* ov = std::getenv("AMENV_PHILOX_WAVE");
+    e->pwave = ov ? ov[0] == '1' : cfg->num_envs <= 32768;
+  }
+  char buf[200];
+  if (e->pwave) std::snprintf(buf, sizeof(buf), "step_kernel_pw<%s,NROT=%d,KW=%d,%s> block=128 (main wave + reset-RNG wave per 64-env tile)",
+                              cfg->dtype == AMENV_F64 ? "double" : "float",
+                              (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
+                              is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
+  else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                 is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), cfg->vehicle.n_joints ? "v2+arm3" : (is_v1(cfg) ? "v1" : "v2"), e->block);

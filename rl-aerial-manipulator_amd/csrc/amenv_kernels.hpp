@@ -225,7 +225,7 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   constexpr int OD = ObsDim<VAR, NJ>::value;
   const int K = KW == 1 ? 1 : P.K;
   if constexpr (NJ > 0) {
-    if constexpr (ROLE != 0) dynamics_arm<T, NROT, KW, AxesZXX, ROLE, X>(P, AA.p, e, act, x);   // two-wave kernel: z,x,x arm only
+    if constexpr (ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_HELPER) dynamics_arm<T, NROT, KW, AxesZXX, ROLE, X>(P, AA.p, e, act, x);   // two-wave kernel: z,x,x arm only
     else if (AA.p.generic_axes) dynamics_arm<T, NROT, KW, AxesAny>(P, AA.p, e, act);   // wave-uniform: one of the two bodies runs
     else dynamics_arm<T, NROT, KW, AxesZXX>(P, AA.p, e, act);
   } else { dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]); }
@@ -244,13 +244,13 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   ep_len_out = 0; ep_ret_out = 0.0f;
   const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   const bool resets = ended && (P.flags & AMENV_FLAG_AUTO_RESET);
-  if constexpr (ROLE == ARM_ROLE_MAIN) x.sync();   // two-wave kernel: the helper has left every lane's 12 reset words in LDS (every step: unconditional barrier)
+  constexpr bool kWordsFromLds = ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_WORDS;
+  if constexpr (kWordsFromLds) x.sync();   // two-wave kernels: the helper has left every lane's 12 reset words in LDS (every step: unconditional barrier)
   if (__ballot(ended) != 0ull) {  // wave-uniform: the whole cold path is skipped by waves with no episode end
     uint32_t r[12];
-    if constexpr (ROLE == ARM_ROLE_MAIN) {
-      const uint32_t* wl = reinterpret_cast<const uint32_t*>(x.base) + kArmXchgSlots * 64 + lane;
+    if constexpr (kWordsFromLds) {
 #pragma unroll
-      for (int k = 0; k < 12; k++) r[k] = wl[k * 64];
+      for (int k = 0; k < 12; k++) r[k] = x.words[k * 64 + lane];
     } else {
       reset_words_wave(C, resets, C.gid0 + i, e.episode, r);  // all lanes take part, lanes 0..2 do the work
     }
@@ -381,6 +381,60 @@ __global__ __launch_bounds__(256) AMENV_STEP_WAVES_ATTR void step_kernel(void* _
 #endif
 }
 
+// Rigid vehicles at small batches: a second wave per 64-env tile does nothing but the reset RNG.  With 4096 envs some tile ends an
+// episode in almost every launch and the launch is as slow as its slowest wave; the 12 Philox words of a reset depend only on (seed,
+// env id, episode), so the helper computes them for every lane while the main wave integrates, and the main wave's cold path starts from
+// the words in LDS (hover-only actions, which end no episode, ran 1.1 us faster than the bench workload before this).
+template <typename T, int NROT, int KW, int VAR>
+__global__ __launch_bounds__(128) void step_kernel_pw(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+                                                      float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                      uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C) {
+  constexpr int OD = ObsDim<VAR, 0>::value;
+  const Head hd{blob, tile_bytes, n_envs};
+  const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging | [12][64] reset words
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  const int i = blockIdx.x * 64 + lane;
+  const bool active = i < hd.n;
+  char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
+  uint32_t* words = reinterpret_cast<uint32_t*>(lds + 64 * OD);
+  if (role != 0) {
+    const int32_t episode = iptr4(tile, lane)->w;
+    uint32_t r[12];
+    reset_words_serial(C, C.gid0 + i, episode, r);
+#pragma unroll
+    for (int k = 0; k < 12; k++) words[k * 64 + lane] = r[k];
+    __syncthreads();   // words published (pairs with the barrier in step_lane)
+    __syncthreads();   // pairs with the main wave's barrier between staging and flushing the observation rows
+    return;
+  }
+  const LdsXchg x{lds, lane, words};
+  const int K = KW == 1 ? 1 : P.K;
+  Env<T, KW> e;
+  load_env<T, KW, 0>(K, tile, lane, e);
+  float act[kActDim];
+  const float4 a = io.actions[min(i, hd.n - 1)];
+  act[0] = a.x; act[1] = a.y; act[2] = a.z; act[3] = a.w;
+  T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
+  const ArmArg<T, 0> AA{0};
+  uint32_t bits = step_lane<T, NROT, KW, VAR, 0, ARM_ROLE_WORDS, LdsXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len,
+                                                                          ep_ret, x);
+  const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+  accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
+  store_env_step<T, KW>(tile, lane, e);
+  if (was_reset) store_env_episode<T, KW, 0>(K, tile, lane, e);
+  if (active) {
+    reinterpret_cast<T*>(io.reward)[i] = reward;
+    io.done[i] = is_done ? 1 : 0;
+    io.info[i] = bits;
+  }
+  stage_obs<OD>(lds + lane * OD, o);
+  __syncthreads();
+  const int row0 = blockIdx.x * 64;
+  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
+}
+
 // Two-wave step kernel for the hexacopter + z,x,x arm at small batches (BASELINE config 3 at 4096 envs = 64 tiles).  One tile of 64
 // environments per 128-thread workgroup: wave 0 ("main") does everything the one-wave kernel does except link 3's part of each RHS,
 // wave 1 ("helper") runs the same RK4 on the same state and contributes link 3 (see amenv_arm.hpp).  A launch of 64 lone waves
@@ -406,10 +460,11 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
   const int i = blockIdx.x * 64 + lane;
   const bool active = i < hd.n;
   char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
+  const uint32_t* words_ = reinterpret_cast<const uint32_t*>(lds + 64 * OD) + kArmXchgSlots * 64;
 #ifdef AMENV_STAMPS
-  const LdsXchg x{lds + 64 * OD, lane, stamps_};
+  const LdsXchg x{lds + 64 * OD, lane, words_, stamps_};
 #else
-  const LdsXchg x{lds + 64 * OD, lane};
+  const LdsXchg x{lds + 64 * OD, lane, words_};
 #endif
   Env<T, KW> e;
   load_env<T, KW, NJ>(1, tile, lane, e);

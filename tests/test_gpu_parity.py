@@ -600,3 +600,35 @@ def test_other_rigid_vehicles_teacher_forced_vs_oracle(amd, vehicle, dtype, tol)
     assert worst < tol, worst
     assert flips <= 3 and dones > 100, (flips, dones)
     env.close()
+
+
+@pytest.mark.parametrize("kw", [dict(vehicle="quad"), dict(vehicle="hexa"), dict(vehicle="quad", task="v1_scaled"), dict(vehicle="quad", dtype="f64"),
+                                dict(vehicle="quad", num_waypoints=3)])
+@pytest.mark.parametrize("n", [65, 1000])
+def test_reset_rng_helper_wave_is_bit_identical(amd, monkeypatch, kw, n):
+    """Small batches of the rigid vehicles run step_kernel_pw: a second wave per tile computes the reset Philox words while the main wave
+    integrates.  Same words, same arithmetic: trajectories, resets, rewards, terminal observations and totals are identical."""
+    torch = _torch()
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("AMENV_PHILOX_WAVE", flag)
+        env = amd.GpuWaypointEnv(n, seed=13, **kw)
+        assert ("step_kernel_pw" in env.kernel_name) == (flag == "1")
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(2)
+        acts = torch.randn(300, n, 4, device="cuda", generator=g) * 0.1
+        acts[..., 0] += 1.0
+        acts[:, ::5, 0] = 0.2                        # every 5th env falls: crashes and auto-resets
+        acts = acts.clamp(-1, 2)
+        rec = []
+        for t in range(300):
+            obs, rew, done, info = env.step(acts[t].clone())
+            d = done.bool()
+            rec.append((obs.clone(), rew.clone(), done.clone(), info.clone(), env.terminal_obs[d].clone(), env.ep_return[d].clone(), env.ep_len[d].clone()))
+        f, i = env.get_state()
+        outs.append((rec, f.clone(), i.clone(), env.stats()))
+        env.close()
+    (r0, f0, i0, s0), (r1, f1, i1, s1) = outs
+    assert torch.equal(f0, f1) and torch.equal(i0, i1) and s0 == s1 and s0["episodes"] > n // 5
+    for a, b in zip(r0, r1):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
