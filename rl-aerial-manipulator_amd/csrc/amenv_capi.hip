@@ -297,7 +297,7 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   }
   if constexpr (NJ == 0) {
     if (T_steps == 0 && e.pwave) {   // one tile per 128-thread workgroup: main wave + reset-RNG wave
-      const dim3 g2(e.n_tiles), b2(128);
+      const dim3 g2(e.n_tiles), b2((KW == 1 && VAR == VAR_V2) ? 192 : 128);   // + an observation wave for the single-waypoint v2 task
       const size_t lds2 = size_t(64 * ObsDim<VAR, 0>::value + 12 * 64) * sizeof(float);
       if (timed) hipExtLaunchKernelGGL((step_kernel_pw<T, NROT, KW, VAR>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
                                        io.done, io.info, tl, P, C);
@@ -466,7 +466,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     e->pwave = ov ? ov[0] == '1' : cfg->num_envs <= 32768;
   }
   char buf[200];
-  if (e->pwave) std::snprintf(buf, sizeof(buf), "step_kernel_pw<%s,NROT=%d,KW=%d,%s> block=128 (main wave + reset-RNG wave per 64-env tile)",
+  if (e->pwave) std::snprintf(buf, sizeof(buf), "step_kernel_pw<%s,NROT=%d,KW=%d,%s> (main wave + reset-RNG wave [+ observation wave] per 64-env tile)",
                               cfg->dtype == AMENV_F64 ? "double" : "float",
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");

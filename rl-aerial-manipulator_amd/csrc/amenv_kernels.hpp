@@ -385,41 +385,60 @@ __global__ __launch_bounds__(256) AMENV_STEP_WAVES_ATTR void step_kernel(void* _
 // episode in almost every launch and the launch is as slow as its slowest wave; the 12 Philox words of a reset depend only on (seed,
 // env id, episode), so the helper computes them for every lane while the main wave integrates, and the main wave's cold path starts from
 // the words in LDS (hover-only actions, which end no episode, ran 1.1 us faster than the bench workload before this).
+// For the single-waypoint v2 task (observation = pure function of the post-step state) a third wave integrates the same step only to
+// compute, stage and flush the observation rows, as the arm kernel's helper does: the main wave is left with dynamics + task step + stores.
 template <typename T, int NROT, int KW, int VAR>
-__global__ __launch_bounds__(128) void step_kernel_pw(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+__global__ __launch_bounds__(192) void step_kernel_pw(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
                                                       float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
                                                       uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C) {
   constexpr int OD = ObsDim<VAR, 0>::value;
+  constexpr bool kObsWave = KW == 1 && VAR == VAR_V2;              // launched with 192 threads then, else with 128
   const Head hd{blob, tile_bytes, n_envs};
   const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging | [12][64] reset words
   const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);   // 0 main, 1 reset-RNG words, 2 observation
   const int i = blockIdx.x * 64 + lane;
   const bool active = i < hd.n;
   char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
   uint32_t* words = reinterpret_cast<uint32_t*>(lds + 64 * OD);
-  if (role != 0) {
+  const int row0 = blockIdx.x * 64;
+  if (role == 1) {
     const int32_t episode = iptr4(tile, lane)->w;
     uint32_t r[12];
     reset_words_serial(C, C.gid0 + i, episode, r);
 #pragma unroll
     for (int k = 0; k < 12; k++) words[k * 64 + lane] = r[k];
     __syncthreads();   // words published (pairs with the barrier in step_lane)
-    __syncthreads();   // pairs with the main wave's barrier between staging and flushing the observation rows
+    __syncthreads();   // pairs with the main wave's last barrier
     return;
   }
-  const LdsXchg x{lds, lane, words};
   const int K = KW == 1 ? 1 : P.K;
   Env<T, KW> e;
   load_env<T, KW, 0>(K, tile, lane, e);
   float act[kActDim];
   const float4 a = io.actions[min(i, hd.n - 1)];
   act[0] = a.x; act[1] = a.y; act[2] = a.z; act[3] = a.w;
+  if constexpr (kObsWave) {
+    if (role == 2) {
+      dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]);
+      float ho[kObsDimMax];
+      observe<T, KW>(1, e, ho);
+      stage_obs<OD>(lds + lane * OD, ho);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
+      __syncthreads();   // (words barrier: this wave only passes through)
+      __syncthreads();   // rows stored and acknowledged before the main wave may overwrite the rows of reset lanes
+      return;
+    }
+  }
+  const LdsXchg x{lds, lane, words};
   T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
   const ArmArg<T, 0> AA{0};
-  uint32_t bits = step_lane<T, NROT, KW, VAR, 0, ARM_ROLE_WORDS, LdsXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len,
-                                                                          ep_ret, x);
+  constexpr int MAIN_ROLE = kObsWave ? ARM_ROLE_MAIN : ARM_ROLE_WORDS;
+  uint32_t bits = step_lane<T, NROT, KW, VAR, 0, MAIN_ROLE, LdsXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len,
+                                                                      ep_ret, x);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
   store_env_step<T, KW>(tile, lane, e);
@@ -429,10 +448,23 @@ __global__ __launch_bounds__(128) void step_kernel_pw(void* __restrict__ blob, u
     io.done[i] = is_done ? 1 : 0;
     io.info[i] = bits;
   }
-  stage_obs<OD>(lds + lane * OD, o);
-  __syncthreads();
-  const int row0 = blockIdx.x * 64;
-  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
+  if constexpr (kObsWave) {
+    __syncthreads();     // the observation wave's rows have landed
+    if (is_done && io.terminal_obs) {   // terminal observation = the pre-reset row staged by the observation wave
+      float* t = io.terminal_obs + size_t(i) * OD;
+#pragma unroll
+      for (int j = 0; j < OD; j++) t[j] = lds[lane * OD + j];
+    }
+    if (was_reset && active) {
+      float* d = io.obs + size_t(i) * OD;
+#pragma unroll
+      for (int j = 0; j < OD; j++) d[j] = o[j];
+    }
+  } else {
+    stage_obs<OD>(lds + lane * OD, o);
+    __syncthreads();
+    flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
+  }
 }
 
 // Two-wave step kernel for the hexacopter + z,x,x arm at small batches (BASELINE config 3 at 4096 envs = 64 tiles).  One tile of 64
