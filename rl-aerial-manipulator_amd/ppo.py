@@ -28,14 +28,14 @@ from torch import nn
 from . import _lib as L
 
 
-_SPLIT = int(os.environ.get("AMENV_PPO_SPLIT", "256"))   # rows per partial product of the weight gradient (tuning override)
+_SPLIT = int(os.environ.get("AMENV_PPO_SPLIT", "1024"))   # rows per partial product of the weight gradient (measured: 128..2048 within 5 %, 1024 best)
 
 
 class _TallSkinnyLinearFn(torch.autograd.Function):
     """y = x W^T + b with a weight gradient shaped for this workload.  dW = dY^T X is a [out, in] <= 128 x 128 result
     reduced over the whole minibatch (65,536 rows): the library GEMM picked for that shape runs in one or two workgroups
     without split-K (rocprof, profiles/r01/ppo_update_kernel_stats_before.csv: ~200 us per call, 55 % of the update).
-    Here the batch is cut into 256-row slabs, one strided-batched GEMM forms the per-slab products on all CUs and a sum
+    Here the batch is cut into 1024-row slabs (256 for small batches), one strided-batched GEMM forms the per-slab products on all CUs and a sum
     over slabs finishes the reduction."""
 
     @staticmethod
@@ -49,9 +49,10 @@ class _TallSkinnyLinearFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gy @ w if ctx.needs_input_grad[0] else None
         rows = x.shape[0]
-        c = rows // _SPLIT
-        m = c * _SPLIT
-        gw = torch.bmm(gy[:m].view(c, _SPLIT, -1).transpose(1, 2), x[:m].view(c, _SPLIT, -1)).sum(0)
+        split = _SPLIT if rows >= 2 * _SPLIT else 256
+        c = rows // split
+        m = c * split
+        gw = torch.bmm(gy[:m].view(c, split, -1).transpose(1, 2), x[:m].view(c, split, -1)).sum(0)
         if m < rows:
             gw = gw + gy[m:].t() @ x[m:]
         return gx, gw, gy.sum(0)
@@ -61,7 +62,7 @@ class _Linear(nn.Linear):
     """nn.Linear (same parameters and state-dict keys) that switches to the tall-skinny weight gradient for big batches."""
 
     def forward(self, x):
-        if x.dim() == 2 and x.shape[0] >= 2 * _SPLIT and torch.is_grad_enabled() and x.is_contiguous():
+        if x.dim() == 2 and x.shape[0] >= 512 and torch.is_grad_enabled() and x.is_contiguous():
             return _TallSkinnyLinearFn.apply(x, self.weight, self.bias)
         return super().forward(x)
 
