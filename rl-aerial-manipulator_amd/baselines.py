@@ -10,7 +10,6 @@ Restates, for N vehicles at once on torch tensors (any device; the GPU-resident 
                            way `PID Controller/runsim.py:26-31` flies its waypoint list.
 Pinned by tests/golden/pid_helix.npz (tools/gen_golden_pid.py: the unmodified reference modules run as runsim.py runs them).
 """
-import math
 
 import torch
 
