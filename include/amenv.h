@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMENV_ABI_VERSION 1
+#define AMENV_ABI_VERSION 2
 
 #define AMENV_MAX_ROTORS 8
 #define AMENV_MAX_WAYPOINTS 4
@@ -50,6 +50,17 @@ extern "C" {
 /* amenv_config.flags */
 #define AMENV_FLAG_AUTO_RESET 1u /* SB3 VecEnv semantics: done envs are reset inside step()      */
 #define AMENV_FLAG_NAN_GUARD 2u  /* non-finite state => terminated|NONFINITE (documented deviation) */
+
+/* amenv_config.step_kernel: which implementation of the SAME step amenv_step() launches.  All of them meet the parity
+ * gate; LANE and HELPER are bit-identical to each other.  AUTO picks by batch size (latency regime vs throughput regime). */
+#define AMENV_KERNEL_AUTO 0
+#define AMENV_KERNEL_LANE 1   /* one lane per env, one wavefront per 64-env tile                                      */
+#define AMENV_KERNEL_HELPER 2 /* LANE + helper wavefronts per tile (reset RNG words, observation rows, arm link 3)     */
+#define AMENV_KERNEL_TEAM 3   /* a team of 4 lanes (one DPP quad) per env: vector components across lanes              */
+
+/* amenv_task.ee_task (arm vehicles only; ignored without an arm) */
+#define AMENV_EE_TASK_BASE 0 /* waypoint distance measured from the base position, as the reference's quadrotor task   */
+#define AMENV_EE_TASK_TOOL 1 /* ... from the arm's tool point (forward kinematics): reward, reach test, obs[13:16]     */
 
 /* task variants (which reference env file the step semantics follow) */
 #define AMENV_TASK_V2_SCALED20 0 /* v2/rl_env_scaledObs.py  (20-D scaled obs) */
@@ -96,6 +107,8 @@ typedef struct amenv_vehicle {
   double joint_acc_max;                      /* rad/s^2 (manipulator_moveit/config/joint_limits.yaml: 8) */
   double joint_reserved;
   double joint_limit[AMENV_MAX_JOINTS * 2];  /* [lower, upper] rad: action -1..1 maps onto it, :105-106,165-166,239-240 */
+  double tool_offset[3];                     /* tool point in the last link's frame: midpoint of the two gripper-finger joint
+                                                origins, manipulator.sdf:371,450 (forward kinematics -> amenv_ee_position, obs, task) */
 } amenv_vehicle;
 
 /* Task constants that the reference keeps as literals in rl_env_scaledObs.py. */
@@ -105,7 +118,7 @@ typedef struct amenv_task {
   int32_t max_episode_steps; /* 2000 (rl_env_scaledObs.py:56) */
   int32_t counter_limit;     /* 500  (rl_env_scaledObs.py:59) */
   int32_t rk4_substeps;      /* RK4 sub-steps per control step; 1 */
-  int32_t reserved0;
+  int32_t ee_task;           /* AMENV_EE_TASK_*: which point of an arm vehicle the waypoint task measures (default TOOL) */
   double dt;                 /* 1/200 (rl_env_scaledObs.py:30) */
   /* sin(2*pi*k/K), cos(2*pi*k/K), k = 1..K: used by the curved / helical waypoint
    * generators (v2/utils2/utils.py:39,46,53,83-87); filled by amenv_default_config(). */
@@ -119,7 +132,9 @@ typedef struct amenv_config {
   int32_t num_envs;     /* N on THIS device */
   int32_t dtype;        /* AMENV_F32 | AMENV_F64 */
   uint32_t flags;       /* AMENV_FLAG_* */
-  int32_t block_size;   /* 0 = auto; else threads per workgroup: 64, 128, 192 or 256 */
+  int32_t block_size;   /* 0 = auto; else threads per workgroup of the LANE kernel: 64, 128 or 256 */
+  int32_t step_kernel;  /* AMENV_KERNEL_*: 0 = auto */
+  int32_t reserved1;
   uint64_t seed;        /* reset RNG seed (Philox4x32-10 key) */
   int64_t env_id_offset; /* global id of local env 0: RNG is keyed by GLOBAL env id, so
                             results do not depend on how envs are sharded over GPUs */
@@ -215,7 +230,9 @@ int amenv_reset(amenv* env, const uint8_t* mask, float* obs_out, void* stream);
  *   quaternion_to_rpy             utils2/utils.py:4-9
  *   DummyVecEnv.step_wait auto-reset + Monitor episode stats (SB3; v2/rl_train.py:24)
  * actions      [N,act_dim] f32 row-major (already clipped by the caller, as SB3 does)
- * obs          [N,obs_dim] f32   next observation (post-reset for done envs when AUTO_RESET)
+ * obs          [N,obs_dim] f32   next observation (post-reset for done envs when AUTO_RESET); obs_dim = 20 (v2 task),
+ *              17 (v1 tasks), 29 with the arm: the 20 v2 entries + joint angles / pi (3) + joint rates / 5 (3) +
+ *              (tool point - base position) / 0.5 in world axes (3)
  * reward       [N] f32 (f64 when dtype = AMENV_F64)
  * done         [N] u8   terminated|truncated
  * info_bits    [N] u32  AMENV_INFO_*
@@ -247,6 +264,12 @@ int amenv_set_state(amenv* env, const void* fstate, const int32_t* istate, void*
 
 /* Recompute observations of the current state (no stepping): _get_observation, :98-121. */
 int amenv_observe(amenv* env, float* obs_out, void* stream);
+
+/* Forward kinematics of the arm (north_star "arm forward kinematics"): world position of the tool point of every env,
+ * ee_out [N,3] f32.  Chain: base pose (p, q) -> joint origins / axes of manipulator.sdf:99,159,233 -> tool_offset (:371,450).
+ * Without an arm (n_joints = 0) the tool point is the body origin.  The same quantity feeds obs[26:29] and, with
+ * AMENV_EE_TASK_TOOL, the waypoint distance inside amenv_step. */
+int amenv_ee_position(amenv* env, float* ee_out, void* stream);
 
 /* Copy the running totals to *host_out (synchronises the stream); optionally zero them. */
 int amenv_stats_read(amenv* env, amenv_stats* host_out, int reset, void* stream);
@@ -288,7 +311,7 @@ int amenv_gaussian_act(const float* mean, const float* log_std, const float* low
  * v2/rl_train.py:27-30) in ONE launch: mean_out [n, act_dim] = action_net(pi trunk(obs)), value_out [n] = value_net(vf trunk(obs));
  * either output may be NULL.  flat_params = the policy's parameters in SB3 state-dict order in one contiguous fp32 buffer
  * (log_std, mlp_extractor.policy_net.{0,2,4}.{weight,bias}, mlp_extractor.value_net.{0,2,4}.{weight,bias}, action_net, value_net:
- * 30,537 floats for 20-D / 4-D).  (obs_dim, act_dim) in {(20,4), (26,7), (17,4)}. */
+ * 30,537 floats for 20-D / 4-D).  (obs_dim, act_dim) in {(20,4), (29,7), (17,4)}. */
 int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, int64_t n, float* mean_out,
                          float* value_out, void* stream);
 

@@ -307,6 +307,29 @@ void orc_arm_rhs(const amenv_config* cfg, const double* s, double F, const doubl
   for (int k = 0; k < 3; k++) { d[13 + k] = k < nj ? thd[k] : 0.0; d[16 + k] = k < nj ? thdd[k] : 0.0; }
 }
 
+/* Forward kinematics of the arm: world position of the tool point.  s = [p(3), v(3), q(4) unit, w(3), th(3), thd(3)].
+ * Chain of revolute joints (manipulator.sdf:99,159,233: origins; :103,163,237: axes) from the body origin O, then
+ * tool_offset in the last link's frame (:371,450), then world = p + Rq^T (body components), Rq as in orc_arm_rhs. */
+void orc_ee_position(const amenv_config* cfg, const double* s, double* ee) {
+  const amenv_vehicle* v = &cfg->vehicle;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+  for (int k = 0; k < v->n_joints; k++) {
+    double Ro[3], Rj[9], Rn[9];
+    matvec3(R, &v->joint_origin[3 * k], Ro);
+    for (int i = 0; i < 3; i++) p[i] += Ro[i];
+    rodrigues(&v->joint_axis[3 * k], s[13 + k], Rj); matmul3(R, Rj, Rn); memcpy(R, Rn, sizeof(R));
+  }
+  double Rt[3];
+  matvec3(R, v->tool_offset, Rt);
+  for (int i = 0; i < 3; i++) p[i] += v->n_joints ? Rt[i] : 0.0;
+  const double n2 = s[6] * s[6] + s[7] * s[7] + s[8] * s[8] + s[9] * s[9], nr = sqrt(n2);
+  const double qw = s[6] / nr, qx = s[7] / nr, qy = s[8] / nr, qz = s[9] / nr;
+  const double Rq[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                        2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                        2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+  for (int i = 0; i < 3; i++) ee[i] = s[i] + Rq[0 + i] * p[0] + Rq[3 + i] * p[1] + Rq[6 + i] * p[2];   /* p + Rq^T ee_body */
+}
+
 /* One control step of the arm vehicle: mixer as for the rigid body, joint commands from actions 4..6, RK4 on 19 states. */
 void orc_arm_dynamics_step(const amenv_config* cfg, double* s, const float* action, double* wrench_out) {
   const amenv_vehicle* v = &cfg->vehicle;
@@ -385,7 +408,12 @@ static void store_env(const amenv_config* cfg, int n, double* f, int32_t* is, in
 }
 
 static int is_v1(const amenv_config* cfg) { return cfg->task.variant == AMENV_TASK_V1_SCALED17 || cfg->task.variant == AMENV_TASK_V1_RAW17; }
-static int obs_dim(const amenv_config* cfg) { return is_v1(cfg) ? 17 : 20 + 2 * cfg->vehicle.n_joints; }
+static int obs_dim(const amenv_config* cfg) { return is_v1(cfg) ? 17 : 20 + 2 * cfg->vehicle.n_joints + (cfg->vehicle.n_joints ? 3 : 0); }
+/* the point the waypoint task measures from: base position, or the arm's tool point (AMENV_EE_TASK_TOOL; this build's extension) */
+static void task_point(const amenv_config* cfg, const env_t* e, double* pt) {
+  if (cfg->vehicle.n_joints && cfg->task.ee_task == AMENV_EE_TASK_TOOL) orc_ee_position(cfg, e->s, pt);
+  else { pt[0] = e->s[0]; pt[1] = e->s[1]; pt[2] = e->s[2]; }
+}
 static int act_dim(const amenv_config* cfg) { return 4 + cfg->vehicle.n_joints; }
 int orc_act_dim(const amenv_config* cfg) { return act_dim(cfg); }
 int orc_obs_dim(const amenv_config* cfg) { return obs_dim(cfg); }
@@ -415,7 +443,8 @@ static void observe_v2(const amenv_config* cfg, const env_t* e, float* obs) {
   for (int c = 0; c < 3; c++) obs[3 + c] = (float)(e->s[3 + c] / 5.0);     /* :113 */
   for (int c = 0; c < 4; c++) obs[6 + c] = (float)(e->s[6 + c]);           /* :114 */
   for (int c = 0; c < 3; c++) obs[10 + c] = (float)(e->s[10 + c] / 5.0);   /* :115 */
-  for (int c = 0; c < 3; c++) obs[13 + c] = (float)((cw[c] - e->s[c]) / 2.0); /* :104,116 */
+  double tp[3]; task_point(cfg, e, tp);
+  for (int c = 0; c < 3; c++) obs[13 + c] = (float)((cw[c] - tp[c]) / 2.0); /* :104,116 */
   for (int c = 0; c < 3; c++) {                                            /* :105-108,117 */
     double rel = 0.0;
     if (!(e->wp_index >= K - 1)) rel = e->wp[e->wp_index + 1][c] - cw[c];
@@ -425,6 +454,10 @@ static void observe_v2(const amenv_config* cfg, const env_t* e, float* obs) {
   for (int k = 0; k < cfg->vehicle.n_joints; k++) {                        /* arm (this build's extension): joint angle / pi, rate / 5 */
     obs[20 + k] = (float)(e->s[13 + k] / PI_D);
     obs[20 + cfg->vehicle.n_joints + k] = (float)(e->s[16 + k] / 5.0);
+  }
+  if (cfg->vehicle.n_joints) {                                             /* (tool point - base position) / 0.5, world axes */
+    double ee[3]; orc_ee_position(cfg, e->s, ee);
+    for (int c = 0; c < 3; c++) obs[20 + 2 * cfg->vehicle.n_joints + c] = (float)((ee[c] - e->s[c]) / 0.5);
   }
 }
 
@@ -468,7 +501,8 @@ static uint32_t env_step_v2(const amenv_config* cfg, env_t* e, const float* acti
   const double* cw = e->wp[idx0];
 
   /* ---- _calculate_reward (:198-231): post-update state, pre-update waypoint/flags */
-  double dvec[3] = {pos[0] - cw[0], pos[1] - cw[1], pos[2] - cw[2]};
+  double tp[3]; task_point(cfg, e, tp);                                    /* = pos for rigid vehicles (the reference) */
+  double dvec[3] = {tp[0] - cw[0], tp[1] - cw[1], tp[2] - cw[2]};
   const double distance = norm3(dvec);                                     /* :204 */
   double distance_reward = -distance * 10;                                 /* :207 */
   const double vn = norm3(vel), wn = norm3(om);
@@ -767,6 +801,16 @@ int orc_rollout(const amenv_config* cfg, double* fstate, int32_t* istate, int T,
     store_env(cfg, n, fstate, istate, i, &e);
     if (reward_sum) reward_sum[i] = acc + o[0] * 0.0;
   }
+  return 0;
+}
+
+/* tool-point positions of every env (forward kinematics), out [N,3] */
+int orc_ee_positions(const amenv_config* cfg, const double* fstate, double* out) {
+  const int n = cfg->num_envs;
+  int32_t* zi = (int32_t*)calloc((size_t)AMENV_I_NFIELDS * n, sizeof(int32_t));
+  if (!zi) return -1;
+  for (int i = 0; i < n; i++) { env_t e; load_env(cfg, n, fstate, zi, i, &e); orc_ee_position(cfg, e.s, out + (size_t)3 * i); }
+  free(zi);
   return 0;
 }
 

@@ -22,6 +22,7 @@ F_FINAL_YAW, F_LAST_DISTANCE, F_EP_RETURN, F_WP0 = 13, 14, 15, 16
 I_STEP, I_COUNTER, I_FLAGS, I_EPISODE, I_NFIELDS = 0, 1, 2, 3, 4
 FLAGBIT_FWR, FLAGBIT_COUNTER_ACTIVE = 256, 512
 TASK_V2_SCALED20, TASK_V1_SCALED17, TASK_V1_RAW17 = 0, 1, 2
+EE_TASK_BASE, EE_TASK_TOOL = 0, 1
 
 
 class Vehicle(C.Structure):
@@ -34,14 +35,14 @@ class Vehicle(C.Structure):
         ("link_mass", C.c_double * MAX_JOINTS), ("link_com", C.c_double * (MAX_JOINTS * 3)),
         ("link_inertia", C.c_double * (MAX_JOINTS * 9)),
         ("joint_kp", C.c_double), ("joint_kd", C.c_double), ("joint_acc_max", C.c_double), ("joint_reserved", C.c_double),
-        ("joint_limit", C.c_double * (MAX_JOINTS * 2)),
+        ("joint_limit", C.c_double * (MAX_JOINTS * 2)), ("tool_offset", C.c_double * 3),
     ]
 
 
 class Task(C.Structure):
     _fields_ = [
         ("variant", C.c_int32), ("num_waypoints", C.c_int32), ("max_episode_steps", C.c_int32),
-        ("counter_limit", C.c_int32), ("rk4_substeps", C.c_int32), ("reserved0", C.c_int32), ("dt", C.c_double),
+        ("counter_limit", C.c_int32), ("rk4_substeps", C.c_int32), ("ee_task", C.c_int32), ("dt", C.c_double),
         ("traj_sin", C.c_double * MAX_WAYPOINTS), ("traj_cos", C.c_double * MAX_WAYPOINTS),
     ]
 
@@ -49,7 +50,7 @@ class Task(C.Structure):
 class Config(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int32), ("dtype", C.c_int32),
-        ("flags", C.c_uint32), ("block_size", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
+        ("flags", C.c_uint32), ("block_size", C.c_int32), ("step_kernel", C.c_int32), ("reserved1", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
         ("vehicle", Vehicle), ("task", Task),
     ]
 
@@ -84,6 +85,8 @@ def lib():
         L.orc_observe.argtypes = [C.POINTER(Config), P, P, P]
         L.orc_step.argtypes = [C.POINTER(Config)] + [P] * 10 + [C.c_int]
         L.orc_rollout.argtypes = [C.POINTER(Config), P, P, C.c_int, P, P, C.c_int]
+        L.orc_ee_position.argtypes = [C.POINTER(Config), P, P]
+        L.orc_ee_positions.argtypes = [C.POINTER(Config), P, P]
         L.orc_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, P]
         L.orc_max_threads.restype = C.c_int
         _lib = L
@@ -129,6 +132,12 @@ class OracleEnv:
         obs = np.zeros((self.n, self.obs_dim), np.float32)
         lib().orc_observe(C.byref(self.cfg), _p(self.fstate), _p(self.istate), _p(obs))
         return obs
+
+    def ee_position(self):
+        """World position of the arm's tool point for every env, [N,3] fp64 (forward kinematics; body origin without an arm)."""
+        out = np.zeros((self.n, 3), np.float64)
+        lib().orc_ee_positions(C.byref(self.cfg), _p(self.fstate), _p(out))
+        return out
 
     def step(self, actions, nthreads=1):
         a = np.ascontiguousarray(actions, np.float32).reshape(self.n, self.act_dim)
@@ -184,6 +193,12 @@ def arm_dynamics_step(cfg, s19, action7):
     s = np.array(s19, np.float64).copy(); a = np.ascontiguousarray(action7, np.float32); w = np.zeros(8)
     lib().orc_arm_dynamics_step(C.byref(cfg), _p(s), _p(a), _p(w))
     return s, w
+
+
+def ee_position(cfg, s19):
+    s = np.ascontiguousarray(s19, np.float64); out = np.zeros(3)
+    lib().orc_ee_position(C.byref(cfg), _p(s), _p(out))
+    return out
 
 
 def philox(seed, gid, episode, block):

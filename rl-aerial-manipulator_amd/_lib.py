@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMENV_LIB") or os.path.join(HERE, "libamenv.so")
 
 MAX_ROTORS, MAX_WAYPOINTS, MAX_JOINTS = 8, 4, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F64 = 0, 1
 FLAG_AUTO_RESET, FLAG_NAN_GUARD = 1, 2
 INFO_TERMINATED, INFO_TRUNCATED, INFO_SUCCESS, INFO_STOPPED, INFO_CRASHED, INFO_OOB, INFO_NONFINITE, INFO_WAS_RESET = (1 << i for i in range(8))
@@ -16,6 +16,9 @@ F_FINAL_YAW, F_LAST_DISTANCE, F_EP_RETURN, F_WP0 = 13, 14, 15, 16
 I_STEP, I_COUNTER, I_FLAGS, I_EPISODE, I_NFIELDS = 0, 1, 2, 3, 4
 FLAGBIT_FWR, FLAGBIT_COUNTER_ACTIVE = 256, 512
 TASK_V2_SCALED20, TASK_V1_SCALED17, TASK_V1_RAW17 = 0, 1, 2
+KERNEL_AUTO, KERNEL_LANE, KERNEL_HELPER, KERNEL_TEAM = 0, 1, 2, 3
+KERNELS = {"auto": KERNEL_AUTO, "lane": KERNEL_LANE, "helper": KERNEL_HELPER, "team": KERNEL_TEAM}
+EE_TASK_BASE, EE_TASK_TOOL = 0, 1
 TASKS = {"v2": TASK_V2_SCALED20, "v1_scaled": TASK_V1_SCALED17, "v1_raw": TASK_V1_RAW17}
 
 
@@ -29,14 +32,14 @@ class Vehicle(C.Structure):
         ("link_mass", C.c_double * MAX_JOINTS), ("link_com", C.c_double * (MAX_JOINTS * 3)),
         ("link_inertia", C.c_double * (MAX_JOINTS * 9)),
         ("joint_kp", C.c_double), ("joint_kd", C.c_double), ("joint_acc_max", C.c_double), ("joint_reserved", C.c_double),
-        ("joint_limit", C.c_double * (MAX_JOINTS * 2)),
+        ("joint_limit", C.c_double * (MAX_JOINTS * 2)), ("tool_offset", C.c_double * 3),
     ]
 
 
 class Task(C.Structure):
     _fields_ = [
         ("variant", C.c_int32), ("num_waypoints", C.c_int32), ("max_episode_steps", C.c_int32),
-        ("counter_limit", C.c_int32), ("rk4_substeps", C.c_int32), ("reserved0", C.c_int32), ("dt", C.c_double),
+        ("counter_limit", C.c_int32), ("rk4_substeps", C.c_int32), ("ee_task", C.c_int32), ("dt", C.c_double),
         ("traj_sin", C.c_double * MAX_WAYPOINTS), ("traj_cos", C.c_double * MAX_WAYPOINTS),
     ]
 
@@ -44,7 +47,7 @@ class Task(C.Structure):
 class Config(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("num_envs", C.c_int32), ("dtype", C.c_int32),
-        ("flags", C.c_uint32), ("block_size", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
+        ("flags", C.c_uint32), ("block_size", C.c_int32), ("step_kernel", C.c_int32), ("reserved1", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
         ("vehicle", Vehicle), ("task", Task),
     ]
 
@@ -77,6 +80,7 @@ SYMBOLS = {
     "amenv_get_state": (C.c_int, [_P] * 4),
     "amenv_set_state": (C.c_int, [_P] * 4),
     "amenv_observe": (C.c_int, [_P, _P, _P]),
+    "amenv_ee_position": (C.c_int, [_P, _P, _P]),
     "amenv_stats_read": (C.c_int, [_P, C.POINTER(Stats), C.c_int, _P]),
     "amenv_kernel_name": (C.c_char_p, [_P]),
     "amenv_obsnorm_create": (C.c_int, [C.c_int32, C.c_int, C.POINTER(_P)]),

@@ -31,6 +31,8 @@ struct ArmParams {
   T mtot, inv_mtot;
   float mid[3], half[3];  // joint command = fmaf(action, half, mid), formed in fp32
   int32_t generic_axes;   // 0: joint axes are (z, x, x) -> AxesZXX fast path; 1: general axes
+  T tool[3];              // tool point in the last link's frame (manipulator.sdf:371,450)
+  T ee_home[3];           // tool point relative to the body origin with the arm at home (all joints 0), formed in fp64 on the host
 };
 
 // Joint-axis pattern of an instantiation: 0/1/2 = the joint axis is +x/+y/+z (compile time, so R's columns are picked by constant
@@ -90,6 +92,44 @@ __device__ __forceinline__ void rotate_about_column(M3<T>& R, T th) {
     R.m[3 * i + a] = fma_(co, ra, s * rb);
     R.m[3 * i + b] = fma_(co, rb, -(s * ra));
   }
+}
+
+// Forward kinematics (north_star "arm forward kinematics"): tool point relative to the body origin in WORLD axes, for the unit
+// quaternion (qw, qx, qy, qz) and joint angles th.  Chain: joint origins / axes (manipulator.sdf:99,159,233 / :103,163,237), then
+// the tool offset in the last link's frame (:371,450); world = Rq^T . body, Rq as in the dynamics below.
+template <typename AX, typename T>
+__device__ __forceinline__ V3<T> ee_offset_world(const ArmParams<T>& A, T qw, T qx, T qy, T qz, const T* th) {
+  V3<T> b;
+  if constexpr (AX::code[0] == 2 && AX::code[1] == 0 && AX::code[2] == 0) {
+    // z, x, x arm: joints 2 and 3 turn about the same axis, so  ee_b = o1 + Rz(th1) (o2 + Rx(th2) o3 + Rx(th2 + th3) tool)
+    T s1, c1, s2, c2, s3, c3;
+    sincos_(th[0], s1, c1); sincos_(th[1], s2, c2); sincos_(th[1] + th[2], s3, c3);
+    const T ux = A.jo[1][0] + A.jo[2][0] + A.tool[0];
+    const T uy = A.jo[1][1] + fma_(c2, A.jo[2][1], -(s2 * A.jo[2][2])) + fma_(c3, A.tool[1], -(s3 * A.tool[2]));
+    const T uz = A.jo[1][2] + fma_(s2, A.jo[2][1], c2 * A.jo[2][2]) + fma_(s3, A.tool[1], c3 * A.tool[2]);
+    b = V3<T>{A.jo[0][0] + fma_(c1, ux, -(s1 * uy)), A.jo[0][1] + fma_(s1, ux, c1 * uy), A.jo[0][2] + uz};
+  } else {
+    M3<T> R{{T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}};
+    b = V3<T>{T(0), T(0), T(0)};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      b = b + mul(R, V3<T>{A.jo[k][0], A.jo[k][1], A.jo[k][2]});
+      R = mul(R, rodrigues(V3<T>{A.ja[k][0], A.ja[k][1], A.ja[k][2]}, th[k]));
+    }
+    b = b + mul(R, V3<T>{A.tool[0], A.tool[1], A.tool[2]});
+  }
+  const T two = T(2);
+  M3<T> Rq;
+  Rq.m[0] = fma_(-two, fma_(qy, qy, qz * qz), T(1)); Rq.m[1] = two * fma_(qx, qy, -(qw * qz)); Rq.m[2] = two * fma_(qx, qz, qw * qy);
+  Rq.m[3] = two * fma_(qx, qy, qw * qz); Rq.m[4] = fma_(-two, fma_(qx, qx, qz * qz), T(1)); Rq.m[5] = two * fma_(qy, qz, -(qw * qx));
+  Rq.m[6] = two * fma_(qx, qz, -(qw * qy)); Rq.m[7] = two * fma_(qy, qz, qw * qx); Rq.m[8] = fma_(-two, fma_(qx, qx, qy * qy), T(1));
+  return mulT(Rq, b);
+}
+// runtime choice of the axis pattern (cold kernels: reset, observe, amenv_ee_position)
+template <typename T>
+__device__ __forceinline__ V3<T> ee_offset_world_any(const ArmParams<T>& A, T qw, T qx, T qy, T qz, const T* th) {
+  if (A.generic_axes) return ee_offset_world<AxesAny>(A, qw, qx, qy, qz, th);
+  return ee_offset_world<AxesZXX>(A, qw, qx, qy, qz, th);
 }
 
 // Two-wave variant (small batches; step_kernel_arm2w): the 64 environments of a tile are integrated by TWO wavefronts of one

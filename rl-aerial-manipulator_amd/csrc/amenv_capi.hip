@@ -102,6 +102,7 @@ void fill_task_defaults(amenv_task* t, int K) {
   t->max_episode_steps = 2000;   // :56
   t->counter_limit = 500;        // :59
   t->rk4_substeps = 1;
+  t->ee_task = AMENV_EE_TASK_BASE;
   t->dt = 1.0 / 200.0;           // :30
   const double pi = 3.14159265358979323846;
   for (int k = 1; k <= K; k++) {
@@ -181,6 +182,8 @@ bool vehicle_hexa_arm(amenv_vehicle* v) {
   v->joint_reserved = 0.0;
   const double lim[6] = {-3.14, 3.14, -1.57, 1.57, -1.57, 1.57};   // manipulator.sdf:105-106,165-166,239-240
   std::memcpy(v->joint_limit, lim, sizeof(lim));
+  const double tool[3] = {-0.0015, 0.003, -0.125};   // midpoint of the gripper-finger joint origins in link 3's frame (manipulator.sdf:371,450)
+  std::memcpy(v->tool_offset, tool, sizeof(tool));
   return true;
 }
 
@@ -204,6 +207,7 @@ HotParams<T, NR> make_hot(const amenv& e) {
   P.n_rotors = v.n_rotors; P.substeps = ns;
   P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit;
   P.flags = c.flags; P.K = c.task.num_waypoints; P.raw_obs = c.task.variant == AMENV_TASK_V1_RAW17 ? 1 : 0;
+  P.ee_task = (v.n_joints > 0 && c.task.ee_task == AMENV_EE_TASK_TOOL) ? 1 : 0;
   return P;
 }
 
@@ -225,6 +229,11 @@ ArmParams<T> make_arm(const amenv& e) {
   const double zxx[9] = {0, 0, 1, 1, 0, 0, 1, 0, 0};
   A.generic_axes = std::memcmp(v.joint_axis, zxx, sizeof(zxx)) == 0 ? 0 : 1;
   A.mtot = T(v.mass); A.inv_mtot = T(1.0 / v.mass);
+  for (int c = 0; c < 3; c++) {
+    A.tool[c] = T(v.tool_offset[c]);
+    // arm at home: every joint rotation is the identity, whatever the axes
+    A.ee_home[c] = v.n_joints > 0 ? T(v.joint_origin[c] + v.joint_origin[3 + c] + v.joint_origin[6 + c] + v.tool_offset[c]) : T(0);
+  }
   return A;
 }
 
@@ -238,7 +247,7 @@ ColdParams make_cold(const amenv& e) {
 }
 
 bool is_v1(const amenv_config* c) { return c->task.variant == AMENV_TASK_V1_SCALED17 || c->task.variant == AMENV_TASK_V1_RAW17; }
-int obs_dim_of(const amenv_config* c) { return is_v1(c) ? 17 : 20 + 2 * c->vehicle.n_joints; }
+int obs_dim_of(const amenv_config* c) { return is_v1(c) ? 17 : 20 + 2 * c->vehicle.n_joints + (c->vehicle.n_joints ? 3 : 0); }
 int act_dim_of(const amenv_config* c) { return kActDim + c->vehicle.n_joints; }
 
 int n_float_fields(const amenv_config* c) { return AMENV_F_WP0 + 3 * c->task.num_waypoints + 2 * c->vehicle.n_joints; }
@@ -269,7 +278,10 @@ const char* validate(const amenv_config* c) {
       if (std::fabs(c->vehicle.inertia[i * 3 + j] - c->vehicle.inertia[j * 3 + i]) > 1e-15 ||
           std::fabs(c->vehicle.inv_inertia[i * 3 + j] - c->vehicle.inv_inertia[j * 3 + i]) > 1e-6 * std::fabs(c->vehicle.inv_inertia[i * 3 + i]))
         return "inertia and inv_inertia must be symmetric";
-  if (c->block_size != 0 && (c->block_size < 64 || c->block_size > 256 || c->block_size % 64)) return "block_size must be 0, 64, 128, 192 or 256";
+  // the blob holds whole 256-lane groups of tiles and padding lanes run unguarded: the workgroup size must divide 256
+  if (c->block_size != 0 && c->block_size != 64 && c->block_size != 128 && c->block_size != 256) return "block_size must be 0, 64, 128 or 256";
+  if (c->step_kernel < AMENV_KERNEL_AUTO || c->step_kernel > AMENV_KERNEL_TEAM) return "unknown step_kernel";
+  if (c->task.ee_task != AMENV_EE_TASK_BASE && c->task.ee_task != AMENV_EE_TASK_TOOL) return "unknown task.ee_task";
   return nullptr;
 }
 
@@ -337,8 +349,17 @@ hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStrea
 template <typename T>
 hipError_t launch_reset(const amenv& e, const uint8_t* mask, float* obs, int pad_only, hipStream_t s) {
   const int bs = 256, n_pad = e.n_tiles * 64;
-  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, n_pad, e.cfg.task.num_waypoints, e.cfg.task.variant, e.cfg.vehicle.n_joints, e.tile_bytes,
-                     make_cold(e), e.blob, mask, obs, pad_only);
+  hipLaunchKernelGGL((reset_kernel<T>), dim3((n_pad + bs - 1) / bs), dim3(bs), 0, s, e.cfg.num_envs, n_pad, e.cfg.task.num_waypoints, e.cfg.task.variant, e.cfg.vehicle.n_joints,
+                     e.cfg.task.ee_task, e.tile_bytes, make_cold(e), make_arm<T>(e), e.blob, mask, obs, pad_only);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_observe(const amenv& e, float* obs, float* ee, hipStream_t s) {
+  const int n = e.cfg.num_envs, bs = 256, K = e.cfg.task.num_waypoints, nj = e.cfg.vehicle.n_joints;
+  if (obs) hipLaunchKernelGGL((observe_kernel<T>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e.cfg.task.variant, nj, e.cfg.task.ee_task, e.tile_bytes, make_arm<T>(e),
+                              (const void*)e.blob, obs);
+  if (ee) hipLaunchKernelGGL((ee_position_kernel<T>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, nj, e.tile_bytes, make_arm<T>(e), (const void*)e.blob, ee);
   return hipGetLastError();
 }
 
@@ -355,7 +376,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 extern "C" {
 
-const char* amenv_version(void) { return "amenv 0.1 (gfx950, abi 1)"; }
+const char* amenv_version(void) { return "amenv 0.2 (gfx950, abi 2)"; }
 
 int amenv_default_config(const char* vehicle_name, int32_t num_envs, amenv_config* cfg) {
   if (!cfg || !vehicle_name) return fail(nullptr, AMENV_ERR_INVALID, "amenv_default_config: NULL argument");
@@ -375,6 +396,8 @@ int amenv_default_config(const char* vehicle_name, int32_t num_envs, amenv_confi
   else return fail(nullptr, AMENV_ERR_INVALID, std::string("unknown vehicle '") + vehicle_name + "' (quad | hexa | hexa_arm)");
   if (!ok) return fail(nullptr, AMENV_ERR_INVALID, "singular vehicle matrices");
   fill_task_defaults(&cfg->task, 1);
+  // north_star: "arm forward kinematics, waypoint reward" -- with the arm the task measures from the tool point
+  cfg->task.ee_task = cfg->vehicle.n_joints > 0 ? AMENV_EE_TASK_TOOL : AMENV_EE_TASK_BASE;
   return AMENV_OK;
 }
 
@@ -454,16 +477,23 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     amenv_destroy(e);
     return fail(nullptr, AMENV_ERR_ALLOC, msg);
   }
+  // Kernel choice (amenv_config.step_kernel; AUTO by batch size).  HELPER variants exist for fp32 z,x,x-arm vehicles (two-wave kernel:
+  // measured faster up to 65536 envs, 18.0 vs 19.5 us there) and for rigid vehicles with the default workgroup size (reset-RNG /
+  // observation helper waves: faster while the launch is latency-bound, up to 32768 envs).
+  const int want = cfg->step_kernel;
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32) {
-    // two-wave kernel while the launch is issue-bound (measured faster up to 65536 envs: 18.0 vs 19.5 us); AMENV_ARM_2WAVE=0/1 overrides
     const ArmParams<float> ap = make_arm<float>(*e);
-    const char* ov = std::getenv("AMENV_ARM_2WAVE");
-    e->arm2w = !ap.generic_axes && (ov ? ov[0] == '1' : cfg->num_envs <= 65536);
+    e->arm2w = !ap.generic_axes && (want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 65536 : want == AMENV_KERNEL_HELPER);
   }
-  if (cfg->vehicle.n_joints == 0 && cfg->block_size == 0) {
-    // rigid vehicles: a reset-RNG helper wave per tile while the launch is latency-bound; AMENV_PHILOX_WAVE=0/1 overrides
-    const char* ov = std::getenv("AMENV_PHILOX_WAVE");
-    e->pwave = ov ? ov[0] == '1' : cfg->num_envs <= 32768;
+  if (cfg->vehicle.n_joints == 0 && cfg->block_size == 0)
+    e->pwave = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 32768 : want == AMENV_KERNEL_HELPER;
+  if (want == AMENV_KERNEL_HELPER && !e->arm2w && !e->pwave) {
+    amenv_destroy(e);
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_HELPER is built for fp32 z,x,x-arm vehicles and for rigid vehicles with block_size = 0");
+  }
+  if (want == AMENV_KERNEL_TEAM) {
+    amenv_destroy(e);
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is not built for this configuration");
   }
   char buf[200];
   if (e->pwave) std::snprintf(buf, sizeof(buf), "step_kernel_pw<%s,NROT=%d,KW=%d,%s> (main wave + reset-RNG wave [+ observation wave] per 64-env tile)",
@@ -514,13 +544,15 @@ int amenv_observe(amenv* e, float* obs_out, void* stream) {
   if (!e || !obs_out) return fail(e, AMENV_ERR_INVALID, "amenv_observe: NULL argument");
   DeviceGuard g(e->device);
   hipStream_t s = (hipStream_t)stream;
-  const int n = e->cfg.num_envs, bs = 256, K = e->cfg.task.num_waypoints;
-  if (e->cfg.dtype == AMENV_F64) {
-    hipLaunchKernelGGL((observe_kernel<double>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->cfg.vehicle.n_joints, e->tile_bytes, (const void*)e->blob, obs_out);
-  } else {
-    hipLaunchKernelGGL((observe_kernel<float>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, K, e->cfg.task.variant, e->cfg.vehicle.n_joints, e->tile_bytes, (const void*)e->blob, obs_out);
-  }
-  AMENV_HIP(e, hipGetLastError());
+  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_observe<double>(*e, obs_out, nullptr, s) : launch_observe<float>(*e, obs_out, nullptr, s));
+  return AMENV_OK;
+}
+
+int amenv_ee_position(amenv* e, float* ee_out, void* stream) {
+  if (!e || !ee_out) return fail(e, AMENV_ERR_INVALID, "amenv_ee_position: NULL argument");
+  DeviceGuard g(e->device);
+  hipStream_t s = (hipStream_t)stream;
+  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_observe<double>(*e, nullptr, ee_out, s) : launch_observe<float>(*e, nullptr, ee_out, s));
   return AMENV_OK;
 }
 
@@ -729,9 +761,9 @@ int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_
   const dim3 grid((unsigned)((n + 63) / 64), 2), block(64 * kPolWaves);
   hipStream_t s = (hipStream_t)stream;
   if (obs_dim == 20 && act_dim == 4) hipLaunchKernelGGL((policy_forward_kernel<20, 4>), grid, block, 0, s, flat_params, obs, (int64_t)n, mean_out, value_out);
-  else if (obs_dim == 26 && act_dim == 7) hipLaunchKernelGGL((policy_forward_kernel<26, 7>), grid, block, 0, s, flat_params, obs, (int64_t)n, mean_out, value_out);
+  else if (obs_dim == 29 && act_dim == 7) hipLaunchKernelGGL((policy_forward_kernel<29, 7>), grid, block, 0, s, flat_params, obs, (int64_t)n, mean_out, value_out);
   else if (obs_dim == 17 && act_dim == 4) hipLaunchKernelGGL((policy_forward_kernel<17, 4>), grid, block, 0, s, flat_params, obs, (int64_t)n, mean_out, value_out);
-  else return AMENV_ERR_INVALID;   // (20,4) v2 | (26,7) hexacopter + arm | (17,4) v1
+  else return AMENV_ERR_INVALID;   // (20,4) v2 | (29,7) hexacopter + arm | (17,4) v1
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

@@ -216,6 +216,15 @@ __device__ __forceinline__ void observe_joints(const Env<T, KW>& e, float* o) { 
     o[20 + k] = float(e.th[k] * T(0.31830988618379067154));
     o[20 + AMENV_MAX_JOINTS + k] = float(e.thd[k] * T(0.2));
   }
+  o[26] = float(e.eox * T(2)); o[27] = float(e.eoy * T(2)); o[28] = float(e.eoz * T(2));   // (tool point - base position) / 0.5
+}
+// forward kinematics of the lane's current state into e.eo* (the joint-axis pattern is wave-uniform)
+template <typename T, int KW, bool ZXX_ONLY>
+__device__ __forceinline__ void update_tool_offset(const ArmParams<T>& A, Env<T, KW>& e) {
+  V3<T> eo;
+  if constexpr (ZXX_ONLY) eo = ee_offset_world<AxesZXX>(A, e.qw, e.qx, e.qy, e.qz, e.th);
+  else eo = ee_offset_world_any(A, e.qw, e.qx, e.qy, e.qz, e.th);
+  e.eox = eo.x; e.eoy = eo.y; e.eoz = eo.z;
 }
 
 template <typename T, int NROT, int KW, int VAR, int NJ, int ROLE = 0, typename X = NoXchg>
@@ -229,14 +238,17 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
     else if (AA.p.generic_axes) dynamics_arm<T, NROT, KW, AxesAny>(P, AA.p, e, act);   // wave-uniform: one of the two bodies runs
     else dynamics_arm<T, NROT, KW, AxesZXX>(P, AA.p, e, act);
   } else { dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]); }
+  constexpr bool EE = NJ > 0;   // arm: forward kinematics of the post-step state feed the task point and the observation
+  if constexpr (EE) update_tool_offset<T, KW, ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_HELPER>(AA.p, e);
+  const bool ee_task = EE && P.ee_task != 0;
   uint32_t bits;
-  if constexpr (VAR == VAR_V1) { bits = task_step_v1<T, KW>(P, e, reward); } else { bits = task_step<T, KW>(P, e, reward); }
+  if constexpr (VAR == VAR_V1) { bits = task_step_v1<T, KW>(P, e, reward); } else { bits = task_step<T, KW, EE>(P, e, reward); }
   e.ep_return += reward;
   // two-wave kernel: the helper wave computes and publishes the observation of every lane; this (main) wave forms one only in the
   // cold path below (terminal observation / post-reset observation of the lanes whose episode ended)
   constexpr bool kLazyObs = ROLE == ARM_ROLE_MAIN;
   auto obs_now = [&]() {
-    if constexpr (VAR == VAR_V1) { observe_v1<T, KW>(P.raw_obs != 0, e, o); } else { observe<T, KW>(K, e, o); }
+    if constexpr (VAR == VAR_V1) { observe_v1<T, KW>(P.raw_obs != 0, e, o); } else { observe<T, KW, EE>(K, e, o, ee_task); }
     if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
   };
   if constexpr (!kLazyObs) obs_now();
@@ -274,6 +286,7 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
         if constexpr (VAR == VAR_V1) { reset_from_words_v1<T, KW>(K, e, r); observe_v1<T, KW>(P.raw_obs != 0, e, o); }
         else {
           reset_from_words<T, KW>(C, K, e, r);
+          if constexpr (EE) { e.eox = AA.p.ee_home[0]; e.eoy = AA.p.ee_home[1]; e.eoz = AA.p.ee_home[2]; }   // level, arm at home
           if constexpr (KW == 1) {
             // observation of a freshly reset env, written out: at rest, level, arm at home, one waypoint -- the same values the general
             // `observe` produces (its products with the zero velocities / rates are +0), ~12 instructions instead of ~130 on the cold path
@@ -282,15 +295,18 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
             o[3] = o[4] = o[5] = 0.0f;
             o[6] = 1.0f; o[7] = o[8] = o[9] = 0.0f;
             o[10] = o[11] = o[12] = 0.0f;
-            o[13] = float((e.wp[0][0] - e.px) * c2); o[14] = float((e.wp[0][1] - e.py) * c2); o[15] = float((e.wp[0][2] - e.pz) * c2);
+            T tx, ty, tz;
+            task_point<EE>(e, ee_task, tx, ty, tz);
+            o[13] = float((e.wp[0][0] - tx) * c2); o[14] = float((e.wp[0][1] - ty) * c2); o[15] = float((e.wp[0][2] - tz) * c2);
             o[16] = o[17] = o[18] = 0.0f;
             o[19] = float(e.final_yaw * T(0.31830988618379067154));
             if constexpr (NJ > 0) {
 #pragma unroll
               for (int k = 0; k < 2 * AMENV_MAX_JOINTS; k++) o[20 + k] = 0.0f;
+              o[26] = float(e.eox * T(2)); o[27] = float(e.eoy * T(2)); o[28] = float(e.eoz * T(2));
             }
           } else {
-            observe<T, KW>(K, e, o);
+            observe<T, KW, EE>(K, e, o, ee_task);
             if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
           }
         }
@@ -550,7 +566,8 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
       x.sync();
     }
     float ho[kObsDimMax];
-    observe<T, KW>(1, e, ho);
+    update_tool_offset<T, KW, true>(AA.p, e);
+    observe<T, KW, true>(1, e, ho, P.ee_task != 0);
     observe_joints<T, KW>(e, ho);
     stage_obs<OD>(lds + lane * OD, ho);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -648,11 +665,23 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
 
 // WaypointQuadEnv.reset for masked envs (mask null = all) + observation of every env.
 // Launched over whole tiles: padding lanes (i >= n) are always reset so that they hold a valid state.
+// joints (read from the tile: they are not part of the generic Env load) + forward kinematics for the cold kernels
+template <typename T, int KW>
+__device__ __forceinline__ void joints_and_tool(const ArmParams<T>& A, int K, int nj, char* tile, int lane, Env<T, KW>& e) {
+#pragma unroll
+  for (int j = 0; j < AMENV_MAX_JOINTS; j++) {
+    e.th[j] = j < nj ? *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j) : T(0);
+    e.thd[j] = j < nj ? *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + nj + j) : T(0);
+  }
+  e.eox = e.eoy = e.eoz = T(0);
+  if (nj > 0) update_tool_offset<T, KW, false>(A, e);
+}
+
 template <typename T>
-__global__ void reset_kernel(int n, int n_pad, int K, int variant, int nj, uint32_t tile_bytes, const ColdParams C, void* __restrict__ blob,
-                             const uint8_t* __restrict__ mask, float* __restrict__ obs, int pad_only) {
+__global__ void reset_kernel(int n, int n_pad, int K, int variant, int nj, int ee_task, uint32_t tile_bytes, const ColdParams C, const ArmParams<T> A,
+                             void* __restrict__ blob, const uint8_t* __restrict__ mask, float* __restrict__ obs, int pad_only) {
   const bool v1 = variant != AMENV_TASK_V2_SCALED20;
-  const int od = v1 ? 17 : 20 + 2 * nj;
+  const int od = v1 ? 17 : 20 + 2 * nj + (nj > 0 ? 3 : 0);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;   // the blob holds n_pad / 64 tiles: nothing exists beyond the last padded lane
   const int lane = threadIdx.x & 63;
@@ -669,34 +698,44 @@ __global__ void reset_kernel(int n, int n_pad, int K, int variant, int nj, uint3
   }
   if (obs && active) {
     float o[kObsDimMax];
+    joints_and_tool<T, AMENV_MAX_WAYPOINTS>(A, K, nj, tile, lane, e);   // (zero joints after a reset)
+    if (do_reset && nj > 0) { e.eox = A.ee_home[0]; e.eoy = A.ee_home[1]; e.eoz = A.ee_home[2]; }   // as the step kernels' reset path
     if (v1) observe_v1<T, AMENV_MAX_WAYPOINTS>(variant == AMENV_TASK_V1_RAW17, e, o);
-    else observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
-    for (int j = 0; j < nj; j++) {   // joints are not in the generic Env load: read them from the tile (zero after a reset)
-      o[20 + j] = float(*fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j) * T(0.31830988618379067154));
-      o[20 + nj + j] = float(*fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + nj + j) * T(0.2));
-    }
+    else observe<T, AMENV_MAX_WAYPOINTS, true>(K, e, o, nj > 0 && ee_task != 0);
+    if (nj > 0) observe_joints<T, AMENV_MAX_WAYPOINTS>(e, o);
     for (int j = 0; j < od; j++) obs[size_t(i) * od + j] = o[j];
   }
 }
 
 // _get_observation of the current state for every env (no stepping).
 template <typename T>
-__global__ void observe_kernel(int n, int K, int variant, int nj, uint32_t tile_bytes, const void* __restrict__ blob, float* __restrict__ obs) {
+__global__ void observe_kernel(int n, int K, int variant, int nj, int ee_task, uint32_t tile_bytes, const ArmParams<T> A, const void* __restrict__ blob,
+                               float* __restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const bool v1 = variant != AMENV_TASK_V2_SCALED20;
-  const int od = v1 ? 17 : 20 + 2 * nj;
+  const int od = v1 ? 17 : 20 + 2 * nj + (nj > 0 ? 3 : 0);
   Env<T, AMENV_MAX_WAYPOINTS> e;
-  load_env<T, AMENV_MAX_WAYPOINTS>(K, tile_base(blob, tile_bytes, i), threadIdx.x & 63, e);
+  char* tile = const_cast<char*>(tile_base(blob, tile_bytes, i));
+  load_env<T, AMENV_MAX_WAYPOINTS>(K, tile, threadIdx.x & 63, e);
+  joints_and_tool<T, AMENV_MAX_WAYPOINTS>(A, K, nj, tile, threadIdx.x & 63, e);
   float o[kObsDimMax];
   if (v1) observe_v1<T, AMENV_MAX_WAYPOINTS>(variant == AMENV_TASK_V1_RAW17, e, o);
-  else observe<T, AMENV_MAX_WAYPOINTS>(K, e, o);
-  char* tile = const_cast<char*>(tile_base(blob, tile_bytes, i));
-  for (int j = 0; j < nj; j++) {
-    o[20 + j] = float(*fptr<T>(tile, threadIdx.x & 63, AMENV_F_WP0 + 3 * K + j) * T(0.31830988618379067154));
-    o[20 + nj + j] = float(*fptr<T>(tile, threadIdx.x & 63, AMENV_F_WP0 + 3 * K + nj + j) * T(0.2));
-  }
+  else observe<T, AMENV_MAX_WAYPOINTS, true>(K, e, o, nj > 0 && ee_task != 0);
+  if (nj > 0) observe_joints<T, AMENV_MAX_WAYPOINTS>(e, o);
   for (int j = 0; j < od; j++) obs[size_t(i) * od + j] = o[j];
+}
+
+// amenv_ee_position: world position of the tool point of every env (forward kinematics of the stored state), out [N][3] f32
+template <typename T>
+__global__ void ee_position_kernel(int n, int K, int nj, uint32_t tile_bytes, const ArmParams<T> A, const void* __restrict__ blob, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Env<T, AMENV_MAX_WAYPOINTS> e;
+  char* tile = const_cast<char*>(tile_base(blob, tile_bytes, i));
+  load_env<T, AMENV_MAX_WAYPOINTS>(K, tile, threadIdx.x & 63, e);
+  joints_and_tool<T, AMENV_MAX_WAYPOINTS>(A, K, nj, tile, threadIdx.x & 63, e);
+  out[size_t(i) * 3] = float(e.px + e.eox); out[size_t(i) * 3 + 1] = float(e.py + e.eoy); out[size_t(i) * 3 + 2] = float(e.pz + e.eoz);
 }
 
 // amenv_get_state / amenv_set_state: the public struct-of-arrays view (fstate [NF][N] T, istate [4][N] i32)

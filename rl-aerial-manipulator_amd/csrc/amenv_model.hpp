@@ -26,8 +26,9 @@ namespace amenv_dev {
 
 constexpr int kActDim = 4;
 enum TaskVar { VAR_V2 = 0, VAR_V1 = 1 };                 // v2/rl_env_scaledObs.py | v1/rl_env_scaledObs.py + v1/rl_env.py
-template <int VAR, int NJ = 0> struct ObsDim { static constexpr int value = VAR == VAR_V1 ? 17 : 20 + 2 * NJ; };   // + joint angle, rate per joint
-constexpr int kObsDimMax = 26;
+// v2 + arm: + joint angle, rate per joint + (tool point - base position) / 0.5 in world axes (forward kinematics)
+template <int VAR, int NJ = 0> struct ObsDim { static constexpr int value = VAR == VAR_V1 ? 17 : 20 + 2 * NJ + (NJ > 0 ? 3 : 0); };
+constexpr int kObsDimMax = 29;
 
 // ---- kernel-argument constants (uniform: they live in SGPRs) ----------------------------------
 // Hot parameters are kept COMPACT (rotor-count-sized mixer, symmetric inertia) so that one batch of
@@ -47,6 +48,7 @@ struct HotParams {
   uint32_t flags;
   int32_t K;                        // waypoints per episode (<= KW of the instantiation); v1: storage bound
   int32_t raw_obs;                  // v1 only: 1 = v1/rl_env.py (unscaled observation)
+  int32_t ee_task;                  // arm vehicles: 1 = the waypoint task measures from the tool point (AMENV_EE_TASK_TOOL)
 };
 
 // Parameters only the reset path needs (cold: loaded when a lane actually resets).
@@ -108,6 +110,8 @@ struct Env {
   T wp[KW][3];
   T final_yaw, last_distance, ep_return;
   T th[AMENV_MAX_JOINTS], thd[AMENV_MAX_JOINTS];   // arm joint angles / rates (unused, and eliminated, without an arm)
+  T eox, eoy, eoz;                                 // arm: tool point - base position, world axes (forward kinematics of the post-step
+                                                   // state; derived, not stored)
   int32_t step, counter, flags, episode;
 };
 
@@ -202,19 +206,30 @@ __device__ __forceinline__ void current_waypoint(int K, const Env<T, KW>& e, int
     if (k < K && idx >= k) { cx = e.wp[k][0]; cy = e.wp[k][1]; cz = e.wp[k][2]; }
 }
 
+// The point the waypoint task measures from: the base position (the reference), or with EE the arm's tool point.
+template <bool EE, typename T, int KW>
+__device__ __forceinline__ void task_point(const Env<T, KW>& e, bool ee_task, T& tx, T& ty, T& tz) {
+  tx = e.px; ty = e.py; tz = e.pz;
+  if constexpr (EE) {
+    if (ee_task) { tx = e.px + e.eox; ty = e.py + e.eoy; tz = e.pz + e.eoz; }
+  }
+}
+
 // _get_observation (rl_env_scaledObs.py:98-121)
-template <typename T, int KW>
-__device__ __forceinline__ void observe(int K, const Env<T, KW>& e, float* o) {
+template <typename T, int KW, bool EE = false>
+__device__ __forceinline__ void observe(int K, const Env<T, KW>& e, float* o, bool ee_task = false) {
   const int idx = e.flags & 15;
   T cx, cy, cz;
   current_waypoint(K, e, idx, cx, cy, cz);
+  T tx, ty, tz;
+  task_point<EE>(e, ee_task, tx, ty, tz);
   // scalings as multiplications by the rounded reciprocal (<= 1 ulp from the reference's divisions)
   const T c10 = T(0.1), c5 = T(0.2), c2 = T(0.5);
   o[0] = float(e.px * c10); o[1] = float(e.py * c10); o[2] = float(e.pz * c10);
   o[3] = float(e.vx * c5); o[4] = float(e.vy * c5); o[5] = float(e.vz * c5);
   o[6] = float(e.qw); o[7] = float(e.qx); o[8] = float(e.qy); o[9] = float(e.qz);
   o[10] = float(e.wx * c5); o[11] = float(e.wy * c5); o[12] = float(e.wz * c5);
-  o[13] = float((cx - e.px) * c2); o[14] = float((cy - e.py) * c2); o[15] = float((cz - e.pz) * c2);
+  o[13] = float((cx - tx) * c2); o[14] = float((cy - ty) * c2); o[15] = float((cz - tz) * c2);
   T nx = T(0), ny = T(0), nz = T(0);
 #pragma unroll
   for (int k = 1; k < KW; k++)
@@ -225,7 +240,7 @@ __device__ __forceinline__ void observe(int K, const Env<T, KW>& e, float* o) {
 
 // One WaypointQuadEnv.step (rl_env_scaledObs.py:123-196) after the dynamics update.
 // Returns info bits; reward in `reward`.  Mutates the episode registers.
-template <typename T, int KW, typename PT>
+template <typename T, int KW, bool EE = false, typename PT>
 __device__ __forceinline__ uint32_t task_step(const PT& P, Env<T, KW>& e, T& reward) {
   const int K = KW == 1 ? 1 : P.K;
   uint32_t bits = 0;
@@ -243,7 +258,9 @@ __device__ __forceinline__ uint32_t task_step(const PT& P, Env<T, KW>& e, T& rew
   T cx, cy, cz;
   current_waypoint(K, e, idx, cx, cy, cz);
   // ---- _calculate_reward (:198-231)
-  const T dx = e.px - cx, dy = e.py - cy, dz = e.pz - cz;
+  T tx, ty, tz;
+  task_point<EE>(e, P.ee_task != 0, tx, ty, tz);
+  const T dx = tx - cx, dy = ty - cy, dz = tz - cz;
   const T dist = sqrt_(dot3_(dx, dy, dz, dx, dy, dz));                    // :204
   T r_dist = T(-10) * dist;                                             // :207
   const T v2 = dot3_(e.vx, e.vy, e.vz, e.vx, e.vy, e.vz);
@@ -504,7 +521,7 @@ __device__ __forceinline__ void reset_from_words(const ColdParams& P, int K, Env
   e.wx = e.wy = e.wz = T(0);
   e.final_yaw = T(fyaw);
 #pragma unroll
-  for (int k = 0; k < AMENV_MAX_JOINTS; k++) { e.th[k] = T(0); e.thd[k] = T(0); }     // arm at home
+  for (int k = 0; k < AMENV_MAX_JOINTS; k++) { e.th[k] = T(0); e.thd[k] = T(0); }     // arm at home (the caller sets the tool offset)
   e.last_distance = T(-1);                                              // :76 None
   e.ep_return = T(0);
   e.step = 0; e.counter = 0; e.flags = 0;                               // :55-59,74-77

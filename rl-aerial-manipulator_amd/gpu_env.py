@@ -32,7 +32,7 @@ class GpuWaypointEnv:
 
     def __init__(self, num_envs, device=0, vehicle="quad", seed=0, dtype="f32", auto_reset=True, nan_guard=False,
                  num_waypoints=1, env_id_offset=0, block_size=0, max_episode_steps=None, counter_limit=None,
-                 rk4_substeps=1, task="v2", config=None):
+                 rk4_substeps=1, task="v2", config=None, kernel="auto", ee_task=None):
         self.lib = L.load()
         self.device_index = _dev_index(device)
         self.device = torch.device("cuda", self.device_index)
@@ -43,6 +43,9 @@ class GpuWaypointEnv:
             cfg.flags = (L.FLAG_AUTO_RESET if auto_reset else 0) | (L.FLAG_NAN_GUARD if nan_guard else 0)
             cfg.env_id_offset = env_id_offset
             cfg.block_size = block_size
+            cfg.step_kernel = L.KERNELS[kernel]   # "auto" | "lane" | "helper" | "team": which implementation of the same step runs
+            if ee_task is not None:               # arm vehicles: "tool" (default) | "base" -- the point the waypoint task measures from
+                cfg.task.ee_task = {"base": L.EE_TASK_BASE, "tool": L.EE_TASK_TOOL}[ee_task]
             cfg.task.rk4_substeps = rk4_substeps
             if max_episode_steps is not None:
                 cfg.task.max_episode_steps = max_episode_steps
@@ -166,6 +169,12 @@ class GpuWaypointEnv:
     def observe(self):
         o = torch.empty(self.num_envs, self.obs_dim, dtype=torch.float32, device=self.device)
         self._check(self.lib.amenv_observe(self._h, C.c_void_p(o.data_ptr()), self._stream()), "amenv_observe")
+        return o
+
+    def ee_position(self):
+        """World position [N,3] f32 of the arm's tool point (forward kinematics of the current state; the body origin without an arm)."""
+        o = torch.empty(self.num_envs, 3, dtype=torch.float32, device=self.device)
+        self._check(self.lib.amenv_ee_position(self._h, C.c_void_p(o.data_ptr()), self._stream()), "amenv_ee_position")
         return o
 
     def get_state(self):

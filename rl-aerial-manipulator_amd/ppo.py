@@ -109,7 +109,7 @@ class ActorCritic(nn.Module):
         self.flat_param = self.flat_grad = None
 
     # ---- forward pieces -----------------------------------------------------------------------
-    _FUSED_DIMS = {(20, 4), (26, 7), (17, 4)}
+    _FUSED_DIMS = {(20, 4), (29, 7), (17, 4)}
 
     def fused_ok(self, obs):
         """The one-launch HIP forward (`amenv_policy_forward`) applies: inference on the GPU, parameters in the flat buffer,

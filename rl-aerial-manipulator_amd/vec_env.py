@@ -101,6 +101,7 @@ class GpuVecEnv(_SB3VecEnv):
         self._actions = None
         self._t0 = time.time()
         self.dt = 1.0 / 200.0  # v2/rl_env_scaledObs.py:30
+        self._pin = self._make_staging(backend)
 
     # ---- VecEnv API ---------------------------------------------------------------------------
     def reset(self):
@@ -113,10 +114,24 @@ class GpuVecEnv(_SB3VecEnv):
     def step_wait(self):
         import torch
         b = self.backend
-        obs, rew, done, bits = b.step(torch.from_numpy(self._actions))
-        obs, rew = self._to_numpy(obs), self._to_numpy(rew).astype(np.float32)
-        done, bits = self._to_numpy(done).astype(bool), self._to_numpy(bits).view(np.uint32)
-        infos = [{} for _ in range(self.num_envs)] if self.num_envs <= 64 else self._sparse_infos(bits)
+        if self._pin is None:   # host-resident backend (the oracle stand-in of the CPU tests)
+            obs, rew, done, bits = b.step(torch.from_numpy(self._actions))
+            obs, rew = self._to_numpy(obs), self._to_numpy(rew).astype(np.float32)
+            done, bits = self._to_numpy(done).astype(bool), self._to_numpy(bits).view(np.uint32)
+        else:
+            # numpy boundary through page-locked staging: one async H2D copy of the actions, the step launch, four async D2H copies,
+            # ONE stream synchronisation (pageable tensors made each of the five copies a blocking staged transfer)
+            P = self._pin
+            np.copyto(P["act_np"], self._actions)
+            P["act_dev"].copy_(P["act"], non_blocking=True)
+            o, r, d, i = b.step(P["act_dev"])
+            P["obs"].copy_(o, non_blocking=True); P["rew"].copy_(r, non_blocking=True)
+            P["done"].copy_(d, non_blocking=True); P["bits"].copy_(i, non_blocking=True)
+            torch.cuda.current_stream(b.device).synchronize()
+            # SB3 keeps `_last_obs` across the next step: hand out copies, never views of the staging buffers
+            obs, rew = P["obs_np"].copy(), P["rew_np"].astype(np.float32)
+            done, bits = P["done_np"].astype(bool), P["bits_np"].view(np.uint32).copy()
+        infos = [{} for _ in range(self.num_envs)]   # one dict PER env: SB3 wrappers write into infos[i]
         ev = np.nonzero(bits & ~np.uint32(L.INFO_WAS_RESET))[0]
         if ev.size:
             dn = ev[done[ev]]
@@ -178,9 +193,20 @@ class GpuVecEnv(_SB3VecEnv):
             return range(self.num_envs)
         return [indices] if isinstance(indices, int) else list(indices)
 
-    def _sparse_infos(self, bits):
-        empty = {}  # one shared empty dict per step for the (vast majority of) envs with nothing to report
-        return [empty] * self.num_envs
+    @staticmethod
+    def _make_staging(backend):
+        """Page-locked host mirrors of the step's inputs / outputs when the backend lives on a GPU; None otherwise."""
+        dev = getattr(backend, "device", None)
+        if dev is None or getattr(dev, "type", "cpu") != "cuda":
+            return None
+        import torch
+        n, od, ad = backend.num_envs, backend.obs_dim, backend.act_dim
+        P = {"act": torch.empty(n, ad, dtype=torch.float32).pin_memory(), "act_dev": torch.empty(n, ad, dtype=torch.float32, device=dev),
+             "obs": torch.empty(n, od, dtype=torch.float32).pin_memory(), "rew": torch.empty(n, dtype=backend.reward.dtype).pin_memory(),
+             "done": torch.empty(n, dtype=torch.uint8).pin_memory(), "bits": torch.empty(n, dtype=torch.int32).pin_memory()}
+        for k in ("act", "obs", "rew", "done", "bits"):
+            P[k + "_np"] = P[k].numpy()
+        return P
 
     @staticmethod
     def _to_numpy(t):

@@ -19,6 +19,7 @@ def arm_cfg(**over):
     pc = amd._lib.default_config("hexa_arm", 1)
     cfg = O.reference_quad_config(1, flags=0)
     C.memmove(C.byref(cfg.vehicle), C.byref(pc.vehicle), C.sizeof(O.Vehicle))
+    cfg.task.ee_task = pc.task.ee_task               # the arm's default: the waypoint task measures from the tool point
     for k, v in over.items():
         setattr(cfg.vehicle, k, v)
     return cfg
@@ -197,3 +198,61 @@ def test_hover_balance_and_servo_tracking():
     np.testing.assert_allclose(s[13:16], w[4:7], atol=2e-3)
     assert abs(w[4] - 1.57) < 1e-6 and abs(w[5] + 0.785) < 1e-6 and abs(w[6] - 1.57) < 1e-6
     assert np.abs(s[16:19]).max() < 1e-2
+
+
+# ---- forward kinematics of the tool point (north_star "arm forward kinematics") -----------------------------
+def fk_numpy(cfg, s):
+    """Independent restatement: chain of Rodrigues rotations about the SDF joint axes, tool offset, body -> world."""
+    v = cfg.vehicle
+    R = np.eye(3); p = np.zeros(3)
+    for k in range(3):
+        p = p + R @ np.array(v.joint_origin[3 * k:3 * k + 3])
+        R = R @ rodrigues(v.joint_axis[3 * k:3 * k + 3], s[13 + k])
+    p = p + R @ np.array(v.tool_offset[:3])
+    return s[0:3] + rot_q(s[6:10]).T @ p
+
+
+def test_forward_kinematics_matches_independent_chain_and_home_invariant():
+    cfg = arm_cfg()
+    rng = np.random.RandomState(0)
+    home = np.array(cfg.vehicle.joint_origin[:9]).reshape(3, 3).sum(0) + np.array(cfg.vehicle.tool_offset[:3])
+    assert abs(home[2] + 0.103522586 + 0.106 + 0.125) < 1e-9 and np.linalg.norm(home) < 0.4     # the tool hangs ~0.33 m below the body origin
+    for _ in range(200):
+        s = np.zeros(19)
+        s[0:3] = rng.normal(0, 2, 3); q = rng.normal(size=4); s[6:10] = q / np.linalg.norm(q)
+        s[13:16] = rng.uniform([-3.14, -1.57, -1.57], [3.14, 1.57, 1.57])
+        np.testing.assert_allclose(O.ee_position(cfg, s), fk_numpy(cfg, s), rtol=0, atol=1e-13)
+        # arm locked at home: the tool point is the base position plus a constant offset rotated by q (VERDICT invariant)
+        s[13:16] = 0
+        np.testing.assert_allclose(O.ee_position(cfg, s), s[0:3] + rot_q(s[6:10]).T @ home, rtol=0, atol=1e-13)
+    # joint 1 turns about body z through the joint origin: the tool stays on a circle around that axis at constant height
+    s = np.zeros(19); s[6] = 1; s[14:16] = (0.7, -0.4)
+    pts = []
+    for th1 in np.linspace(-3, 3, 13):
+        s[13] = th1; pts.append(O.ee_position(cfg, s) - np.array(cfg.vehicle.joint_origin[:3]))
+    pts = np.array(pts)
+    assert np.ptp(pts[:, 2]) < 1e-13 and np.ptp(np.hypot(pts[:, 0], pts[:, 1])) < 1e-13
+
+
+def test_tool_point_task_measures_from_the_end_effector():
+    """AMENV_EE_TASK_TOOL (the arm's default): reward distance, reach test and obs[13:16] use the tool point; _BASE the base position."""
+    outs = {}
+    for mode in (O.EE_TASK_TOOL, O.EE_TASK_BASE):
+        cfg = arm_cfg(); cfg.num_envs = 2; cfg.task.ee_task = mode
+        orc = O.OracleEnv(cfg)
+        orc.reset()
+        assert orc.obs_dim == 29
+        ee = orc.ee_position()
+        # env 0: waypoint 5 cm from the tool point (inside the 0.1 ball), ~0.3 m from the base; env 1: 5 cm from the base
+        orc.fstate[O.F_WP0:O.F_WP0 + 3, 0] = ee[0] + [0.05, 0, 0]
+        orc.fstate[O.F_WP0:O.F_WP0 + 3, 1] = orc.fstate[0:3, 1] + [0.05, 0, 0]
+        a = np.tile(np.array([1, 0, 0, 0, 0, 0, 0], np.float32), (2, 1))
+        o = orc.step(a)
+        outs[mode] = o
+        ee1 = orc.ee_position()
+        ref = ee1 if mode == O.EE_TASK_TOOL else orc.fstate[0:3].T
+        np.testing.assert_allclose(o["obs"][:, 13:16], (orc.fstate[O.F_WP0:O.F_WP0 + 3].T - ref) / 2, atol=1e-7)
+        np.testing.assert_allclose(o["obs"][:, 26:29], (ee1 - orc.fstate[0:3].T) / 0.5, atol=1e-7)
+    tool, base = outs[O.EE_TASK_TOOL]["info"], outs[O.EE_TASK_BASE]["info"]
+    assert (tool[0] & O.INFO_SUCCESS) and not (tool[1] & O.INFO_SUCCESS)
+    assert (base[1] & O.INFO_SUCCESS) and not (base[0] & O.INFO_SUCCESS)

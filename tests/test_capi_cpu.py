@@ -26,7 +26,13 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     cfg = amd._lib.default_config("quad", 4096)
     assert cfg.struct_size == C.sizeof(amd._lib.Config) == C.sizeof(O.Config)
-    assert cfg.abi_version == 1 and cfg.num_envs == 4096 and cfg.flags == amd._lib.FLAG_AUTO_RESET
+    assert cfg.abi_version == 2 and cfg.num_envs == 4096 and cfg.flags == amd._lib.FLAG_AUTO_RESET
+    assert cfg.step_kernel == amd._lib.KERNEL_AUTO and cfg.task.ee_task == amd._lib.EE_TASK_BASE
+    arm = amd._lib.default_config("hexa_arm", 8)
+    assert arm.task.ee_task == amd._lib.EE_TASK_TOOL and list(arm.vehicle.tool_offset) == [-0.0015, 0.003, -0.125]
+    od = C.c_int32(); ad = C.c_int32()
+    amd._lib.load().amenv_dims(C.byref(arm), C.byref(od), C.byref(ad), None, None)
+    assert (od.value, ad.value) == (29, 7)
 
 
 def test_default_quad_equals_oracle_constants():
@@ -72,6 +78,13 @@ def test_bad_config_is_refused():
     cfg = amd._lib.default_config("quad", 16)
     cfg.task.num_waypoints = 9
     assert L.amenv_create(C.byref(cfg), 0, C.byref(h)) == -1
+    # workgroup sizes that do not divide the 256-lane allocation granule are refused (192 used to be accepted and ran past the blob)
+    for bs, ok in ((64, True), (128, True), (256, True), (192, False), (32, False), (512, False)):
+        cfg = amd._lib.default_config("quad", 4096); cfg.block_size = bs
+        rc = L.amenv_create(C.byref(cfg), 0, C.byref(h))
+        assert (b"block_size" in L.amenv_last_error(None)) == (not ok), (bs, rc, L.amenv_last_error(None))
+    cfg = amd._lib.default_config("quad", 16); cfg.step_kernel = 9
+    assert L.amenv_create(C.byref(cfg), 0, C.byref(h)) == -1 and b"step_kernel" in L.amenv_last_error(None)
     with pytest.raises(amd.AmenvError):
         amd._lib.default_config("octo", 1)
 

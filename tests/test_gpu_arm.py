@@ -46,13 +46,18 @@ def test_arm_dims_and_reset():
     import rl_aerial_manipulator_amd as amd
     n = 1000
     env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=5)
-    assert (env.obs_dim, env.act_dim, env.n_float_fields) == (26, 7, 25) and "arm" in env.kernel_name
+    assert (env.obs_dim, env.act_dim, env.n_float_fields) == (29, 7, 25) and "arm" in env.kernel_name
     orc = orc_arm(n, seed=5)
     obs = env.reset().cpu().numpy(); oobs = orc.reset()
     f, i = gpu_state(env)
     assert np.array_equal(f, orc.fstate) and np.array_equal(i, orc.istate) and (f[19:25] == 0).all()
-    np.testing.assert_allclose(obs, oobs, rtol=OBS_ULP, atol=1e-9)
-    assert env.bytes_per_env_step == 4 * (13 + 3 + 3 + 6) + 12 + 28 + 4 * (15 + 6) + 12 + 104 + 4 + 1 + 4
+    # obs[13:16] = (waypoint - (base + tool offset)) / 2: the fp32 sum base + offset rounds once more than the rigid observation
+    np.testing.assert_allclose(obs, oobs, rtol=OBS_ULP, atol=1.5e-7)
+    # at home and level the tool point hangs at a constant offset below the base (forward kinematics with all joints at 0)
+    home = np.array(orc.cfg.vehicle.joint_origin[:9]).reshape(3, 3).sum(0) + np.array(orc.cfg.vehicle.tool_offset[:3])
+    np.testing.assert_allclose(obs[:, 26:29], np.tile(home / 0.5, (n, 1)), rtol=2e-7)
+    np.testing.assert_allclose(env.ee_position().cpu().numpy(), orc.ee_position(), rtol=0, atol=3e-7)
+    assert env.bytes_per_env_step == 4 * (13 + 3 + 3 + 6) + 12 + 28 + 4 * (15 + 6) + 12 + 116 + 4 + 1 + 4
     env.close()
 
 
@@ -142,29 +147,28 @@ def test_arm_rollout_equals_steps_and_vecenv():
     e1 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30); e2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, max_episode_steps=30)
     e1.reset(); e2.reset()
     ro = e1.rollout(at)
-    assert ro["obs"].shape == (T, n, 26)
+    assert ro["obs"].shape == (T, n, 29)
     for t in range(T):
         obs, rew, done, info = e2.step(at[t])
         assert torch.equal(ro["obs"][t], obs) and torch.equal(ro["reward"][t], rew) and torch.equal(ro["info_bits"][t], info)
     assert ro["done"].sum().item() > 0
     ve = amd.GpuVecEnv(num_envs=64, vehicle="hexa_arm")
-    assert ve.observation_space.shape == (26,) and ve.action_space.shape == (7,)
-    assert ve.reset().shape == (64, 26)
+    assert ve.observation_space.shape == (29,) and ve.action_space.shape == (7,)
+    assert ve.reset().shape == (64, 29)
     o, r, d, inf = ve.step(np.tile(np.array([1, 0, 0, 0, 0.2, -0.2, 0.1], np.float32), (64, 1)))
-    assert o.shape == (64, 26) and np.isfinite(o).all()
+    assert o.shape == (64, 29) and np.isfinite(o).all()
     e1.close(); e2.close(); ve.close()
 
 
-def test_two_wave_kernel_is_bit_identical_to_one_wave_kernel(monkeypatch):
+def test_two_wave_kernel_is_bit_identical_to_one_wave_kernel():
     """Small batches run step_kernel_arm2w (main + helper wave per 64-env tile, link 3 on the helper); its partial sums are
     added in the one-wave kernel's order, so whole trajectories -- resets, rewards, observations included -- are identical."""
     import torch
     import rl_aerial_manipulator_amd as amd
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("AMENV_ARM_2WAVE", flag)
-        env = amd.GpuWaypointEnv(300, vehicle="hexa_arm", seed=9)
-        assert ("arm2w" in env.kernel_name) == (flag == "1")
+    for kern in ("lane", "helper"):               # amenv_config.step_kernel: AMENV_KERNEL_LANE / AMENV_KERNEL_HELPER
+        env = amd.GpuWaypointEnv(300, vehicle="hexa_arm", seed=9, kernel=kern)
+        assert ("arm2w" in env.kernel_name) == (kern == "helper")
         env.reset()
         g = torch.Generator(device="cuda").manual_seed(5)
         acts = torch.randn(400, 300, 7, device="cuda", generator=g) * 0.3
@@ -190,14 +194,13 @@ def test_two_wave_kernel_is_bit_identical_to_one_wave_kernel(monkeypatch):
 
 
 @pytest.mark.parametrize("n", [1, 63, 65, 129])
-def test_two_wave_kernel_ragged_batches(monkeypatch, n):
+def test_two_wave_kernel_ragged_batches(n):
     """Batches that do not fill their last tile: the two kernels still agree bit for bit and nothing is written past row n."""
     import torch
     import rl_aerial_manipulator_amd as amd
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("AMENV_ARM_2WAVE", flag)
-        env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=2)
+    for kern in ("lane", "helper"):
+        env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=2, kernel=kern)
         env.reset()
         g = torch.Generator(device="cuda").manual_seed(1)
         acts = (torch.randn(60, n, 7, device="cuda", generator=g) * 0.3)
@@ -237,3 +240,42 @@ def test_arm_long_run_stays_finite():
     f, _ = env.get_state()
     assert s["nonfinite"] == 0 and bool(torch.isfinite(f).all()) and bool(torch.isfinite(env.obs).all())
     assert s["episodes"] > 10000 and s["episodes"] == s["terminated"] + s["truncated"]
+
+
+@pytest.mark.parametrize("ee_task", ["tool", "base"])
+def test_forward_kinematics_and_tool_point_task_vs_oracle(ee_task):
+    """amenv_ee_position / obs[26:29] (forward kinematics) and the task point of the reward / reach test against the fp64 oracle, on
+    random attitudes and joint angles, for both task modes; a third of the envs sit with the TASK point inside the waypoint ball."""
+    import rl_aerial_manipulator_amd as amd
+    n = 4096
+    rng = np.random.RandomState(11)
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, ee_task=ee_task, kernel="lane")
+    orc = orc_arm(n, seed=4)
+    orc.cfg.task.ee_task = O.EE_TASK_TOOL if ee_task == "tool" else O.EE_TASK_BASE
+    env.reset()
+    f, i = gpu_state(env)
+    q = rng.normal(size=(4, n)); q[0] += 2; q /= np.linalg.norm(q, axis=0)
+    f[6:10] = q
+    f[19:22] = rng.uniform([[-3.1], [-1.5], [-1.5]], [[3.1], [1.5], [1.5]], (3, n))
+    f[22:25] = rng.normal(0, 0.5, (3, n)); f[10:13] = rng.normal(0, 0.3, (3, n))
+    env.set_state(f.astype(np.float32), i)
+    f, i = gpu_state(env)
+    orc.fstate[:] = f; orc.istate[:] = i
+    ee_g = env.ee_position().cpu().numpy(); ee_o = orc.ee_position()
+    assert np.abs(ee_g - ee_o).max() < 2e-6
+    assert np.linalg.norm(ee_o - f[0:3].T, axis=1).min() > 0.05 and np.linalg.norm(ee_o - f[0:3].T, axis=1).max() < 0.4
+    assert rel_err(env.observe().cpu().numpy(), orc.observe()).max() < REL32
+    # put the waypoint next to the task point of a third of the envs (the other point is ~0.3 m away: outside the ball)
+    sel = rng.rand(n) < 0.33
+    tp = ee_o if ee_task == "tool" else f[0:3].T
+    f[O.F_WP0:O.F_WP0 + 3, sel] = (tp[sel] + rng.normal(0, 0.03, (sel.sum(), 3))).T
+    env.set_state(f.astype(np.float32), i)
+    a = rand_actions(rng, n)
+    g, o = both_step(env, orc, a)
+    bad = (g["info"] & 127) != (o["info"] & 127)
+    assert bad.sum() <= 6, bad.sum()
+    ok = ~bad
+    assert ((o["info"][ok] & O.INFO_SUCCESS) != 0).sum() > n // 5
+    assert rel_err(g["obs"][ok], o["obs"][ok]).max() < REL32
+    assert (np.abs(g["reward"] - o["reward"]) / np.maximum(1, np.abs(o["reward"])))[ok].max() < 5e-5
+    env.close()

@@ -184,7 +184,7 @@ def test_ppo_with_arm_env_and_obs_normalizer():
     norm = amd.ObsNormalizer(env.obs_dim, device=env.device_index)
     algo = PPO(env, n_steps=32, batch_size=4096, n_epochs=2, seed=0, obs_normalizer=norm)
     algo.learn(2 * 32 * 512)
-    assert algo.policy.num_parameters() == 2 * (26 * 128 + 128 + 128 * 64 + 64 + 64 * 64 + 64) + 64 * 7 + 7 + 64 + 1 + 7
+    assert algo.policy.num_parameters() == 2 * (29 * 128 + 128 + 128 * 64 + 64 + 64 * 64 + 64) + 64 * 7 + 7 + 64 + 1 + 7
     assert all(math.isfinite(v) for rec in algo.log for v in rec.values())
     mean, var, count = norm.get()
     assert abs(count - (2 * 32 + 1) * 512) < 1.0
@@ -251,7 +251,7 @@ def test_fused_ppo_loss_kernel_matches_autograd(A, normalize):
     gradients in three launches) against the torch expression of SB3's loss differentiated by autograd, in fp64."""
     from rl_aerial_manipulator_amd.ppo import MinibatchStep
     torch.manual_seed(A)
-    n, D = 10007, 20 if A == 4 else 26
+    n, D = 10007, 20 if A == 4 else 29
     dev = "cuda"
     pol = ActorCritic(D, A).to(dev).flatten_()
     with torch.no_grad():
@@ -292,7 +292,7 @@ def test_fused_ppo_loss_kernel_matches_autograd(A, normalize):
     assert float((pol.flat_grad.double() - g_ref).abs().max() / scale) < 2e-5
 
 
-@pytest.mark.parametrize("D,A", [(20, 4), (26, 7), (17, 4)])
+@pytest.mark.parametrize("D,A", [(20, 4), (29, 7), (17, 4)])
 @pytest.mark.parametrize("n", [1, 64, 1000, 32768])
 def test_fused_policy_forward_matches_torch_modules(D, A, n):
     """amenv_policy_forward (one launch: scalar-operand weights, LDS activations) against the torch modules it replaces on the

@@ -201,9 +201,9 @@ def test_policy_pth_round_trip(tmp_path):
 
 
 def test_arm_policy_dimensions():
-    pol = ActorCritic(26, 7)
+    pol = ActorCritic(29, 7)
     assert pol.action_low.tolist() == [0.0] + [-1.0] * 6 and pol.action_high.tolist() == [2.0] + [1.0] * 6
-    a = pol.predict(torch.randn(3, 26) * 100)
+    a = pol.predict(torch.randn(3, 29) * 100)
     assert a.shape == (3, 7) and bool((a >= pol.action_low).all()) and bool((a <= pol.action_high).all())
 
 

@@ -67,6 +67,7 @@ def main():
     print("\n== links (mass, CoM in link frame, inertia about CoM) ==")
     for n, (m, c, I) in (("link1 arm_motor_2", (m1, c1, I1)), ("link2 h_arm", (m2, c2, I2)), ("link3 arm_motor_3 + closed gripper", (M3, C3, I3c))):
         print(f"{n}: m={m:.6f} c={c}\n{I}")
+    print(f"tool point in link-3 frame (midpoint of the joint_4 / joint_5 origins, :371,450): {0.5 * (jo['joint_4'] + jo['joint_5'])}")
     print(f"\ntotal mass {M0 + m1 + m2 + M3:.6f} kg (hexa {m_h:.4f} + arm {m_bp + m1 + m2 + M3:.4f})")
     # rotor positions relative to O (x, y matter; thrust is along body z)
     print(f"rotor xy offsets from O: dx={-C0[0]:.3e} dy={-C0[1]:.3e}")
