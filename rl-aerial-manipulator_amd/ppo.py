@@ -525,10 +525,14 @@ class PPO:
                           b.advantages.reshape(n), b.returns.reshape(n), batch_size=self.batch_size, n_epochs=self.n_epochs,
                           generator=self._gen, step=self._step)
 
-    def learn(self, total_timesteps, log_fn=None):
-        """`model.learn(total_timesteps)` (v2/rl_train.py:56): alternate rollouts and updates until the whole job has taken
-        `total_timesteps` env steps.  Per iteration one record: losses + the Monitor episode statistics of the rollout."""
+    def learn(self, total_timesteps, log_fn=None, save_freq=None, save_path=None, name_prefix="ppo_model"):
+        """`model.learn(total_timesteps, callback=CheckpointCallback(save_freq, save_path, name_prefix))` (v2/rl_train.py:14-18,56):
+        alternate rollouts and updates until the whole job has taken `total_timesteps` env steps.  Per iteration one record: losses +
+        the Monitor episode statistics of the rollout.  `save_freq` counts env steps of the whole job (SB3 counts `VecEnv.step`
+        calls: the reference's 12,500 calls x 8 envs = 100,000 steps); rank 0 writes `<save_path>/<name_prefix>_<steps>_steps.zip`
+        at the first iteration boundary at or past every multiple."""
         target = self.num_timesteps + int(total_timesteps)
+        next_save = None if not save_freq else (self.num_timesteps // int(save_freq) + 1) * int(save_freq)
         while self.num_timesteps < target:
             self.env.stats(reset=True)
             self.collect_rollouts()
@@ -540,6 +544,11 @@ class PPO:
             self.log.append(rec)
             if log_fn is not None:
                 log_fn(rec)
+            if next_save is not None and self.num_timesteps >= next_save:
+                if self.dist is None or self.dist.get_rank() == 0:
+                    os.makedirs(save_path or ".", exist_ok=True)
+                    self.save(os.path.join(save_path or ".", f"{name_prefix}_{self.num_timesteps}_steps"))
+                next_save = (self.num_timesteps // int(save_freq) + 1) * int(save_freq)
         return self
 
     def predict(self, obs, deterministic=True):
@@ -555,7 +564,7 @@ class PPO:
         path = path if str(path).endswith(".zip") else str(path) + ".zip"
         data = {k: getattr(self, k) for k in ("n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range", "ent_coef",
                                               "vf_coef", "max_grad_norm", "normalize_advantage", "num_timesteps", "seed")}
-        data.update(learning_rate=self.optimizer.param_groups[0]["lr"], net_arch=list(self.policy.net_arch),
+        data.update(format="amenv-ppo", draw=int(self._draw), learning_rate=self.optimizer.param_groups[0]["lr"], net_arch=list(self.policy.net_arch),
                     obs_dim=self.policy.obs_dim, act_dim=self.policy.act_dim)
         with zipfile.ZipFile(path, "w") as z:
             for name, obj in (("policy.pth", {k: v.detach().cpu().clone() for k, v in self.policy.state_dict().items()}),
@@ -578,6 +587,34 @@ class PPO:
                 if tuple(sd[k].shape) != tuple(v.shape):
                     raise L.AmenvError(f"{k}: checkpoint shape {tuple(sd[k].shape)} != policy {tuple(v.shape)}")
                 v.copy_(torch.as_tensor(sd[k]).to(v.device))
+        return self
+
+    def load(self, path):
+        """Full resume from a zip written by `save()`: weights, Adam moments / step count, learning rate and the timestep counter
+        (`PPO.load(CHECKPOINT_PATH, env=...)` followed by `learn`, v2/rl_train.py:33-35,56).  An SB3 archive has no optimiser state
+        this class can read without unpickling: for those use `load_policy` (weights only)."""
+        with zipfile.ZipFile(path if str(path).endswith(".zip") else str(path) + ".zip") as z:
+            self.load_policy(torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True))
+            names = z.namelist()
+            data = json.loads(z.read("data")) if "data" in names else {}
+            if "policy.optimizer.pth" in names and data.get("format") == "amenv-ppo":
+                osd = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=True)
+                cur = self.optimizer.state_dict()
+                if len(osd["param_groups"]) != len(cur["param_groups"]):
+                    raise L.AmenvError("optimizer state of the checkpoint does not match this optimizer")
+                # copy into the live tensors: a captured update graph keeps pointing at them
+                st = self.optimizer.state[self._leaf]
+                src = osd["state"].get(0, {})
+                if src:
+                    if not st:   # Adam creates its moments lazily
+                        st["step"] = torch.zeros((), dtype=torch.float32, device=self.device)
+                        st["exp_avg"] = torch.zeros_like(self._leaf); st["exp_avg_sq"] = torch.zeros_like(self._leaf)
+                    for k in ("step", "exp_avg", "exp_avg_sq"):
+                        st[k].copy_(torch.as_tensor(src[k]).to(st[k].device))
+                for g, gs in zip(self.optimizer.param_groups, osd["param_groups"]):
+                    g["lr"] = gs["lr"]
+            self.num_timesteps = int(data.get("num_timesteps", self.num_timesteps))
+            self._draw = int(data.get("draw", self._draw))   # action-noise counter: resumed rollouts draw fresh noise
         return self
 
 

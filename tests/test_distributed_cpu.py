@@ -82,3 +82,28 @@ def test_shard_arithmetic():
         assert sh.env_id_offset == r * 4096 and sh.global_envs == 32768
     assert ids == list(range(32768))
     assert amd.sharding.max_over_ranks(None, 0.25) == 0.25 and amd.sharding.sum_counters(None, {"a": 3}) == {"a": 3}
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts 2 ranks as CHILD processes (before it touches torch
+    or a GPU) and relays rank 0's JSON line.  --dry-run replaces the HIP step by a no-op so the launcher, the process group (gloo
+    here, RCCL on GPUs), the barrier / max-over-ranks timing and the line's fields can be checked without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run", "--backend", "gloo",
+                        "--preroll", "8", "--repeats", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert out["config"]["global_envs"] == 2 * 4096 and out["config"]["launch_mode"] == "eager" and out["config"]["eager_launches_per_window"] == 20
+    assert len(out["per_rank_device_ms_per_step"]) == 2 and out["windows"]["count"] == 3
+    assert out["value"] > 0 and abs(out["value"] - 2 * 4096 * 20 / (out["ms_per_step"] * 1e-3 * 20)) < 1e-6 * out["value"]
+    assert out["metric"] == "env-steps/sec (whole node), hexacopter+arm waypoint task at 4096 envs/GPU"
+    # a failing rank must fail the whole command (no line, non-zero exit)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--vehicle", "nonsense"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=280)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

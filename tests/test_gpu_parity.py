@@ -337,17 +337,25 @@ def test_sharding_invariance(amd):
     full.close()
 
 
+@pytest.mark.parametrize("vehicle", ["quad", "hexa", "hexa_arm"])
 @pytest.mark.parametrize("n", [4096, 32768, 262144])
-def test_full_size_properties(amd, n):
-    """BASELINE sizes: size-independent invariants + determinism + Monitor totals."""
+def test_full_size_properties(amd, n, vehicle):
+    """BASELINE sizes (configs[1..3]: 4096 envs; 32768 per GPU; 262144 = the 8-GPU job's total), every vehicle, each with the kernel
+    AUTO selects at that size (helper-wave kernels up to 32768 / 65536 envs, the one-lane-per-env kernel above): size-independent
+    invariants + determinism + Monitor totals."""
     torch = _torch()
     g = torch.Generator(device="cuda").manual_seed(1)
-    lo = torch.tensor([0.0, -1, -1, -1], device="cuda"); hi = torch.tensor([2.0, 1, 1, 1], device="cuda")
+    ad = 7 if vehicle == "hexa_arm" else 4
+    lo = torch.tensor([0.0] + [-1.0] * (ad - 1), device="cuda"); hi = torch.tensor([2.0] + [1.0] * (ad - 1), device="cuda")
     T = 50
-    acts = [lo + (hi - lo) * torch.rand(n, 4, device="cuda", generator=g) for _ in range(T)]
+    acts = [lo + (hi - lo) * torch.rand(n, ad, device="cuda", generator=g) for _ in range(T)]
+    if vehicle != "quad":   # drop a share of the heavier airframes as well (a 40-step time limit ends every episode inside the window)
+        for a in acts:
+            a[::5, 0] = 0.0
     runs = []
     for rep in range(2):
-        env = amd.GpuWaypointEnv(n, seed=9)
+        env = amd.GpuWaypointEnv(n, seed=9, vehicle=vehicle, max_episode_steps=40)
+        assert ("arm2w" in env.kernel_name) == (vehicle == "hexa_arm" and n <= 65536) and ("_pw" in env.kernel_name) == (vehicle != "hexa_arm" and n <= 32768)
         env.reset()
         ndone = 0; ret = 0.0
         for t in range(T):
@@ -366,9 +374,12 @@ def test_full_size_properties(amd, n):
         assert (qn - 1).abs().max().item() < 1e-6
         # observation is the documented function of the state
         assert torch.allclose(obs[:, 0:3], (f[0:3] / 10).T, atol=1e-7) and torch.equal(obs[:, 6:10], f[6:10].T.contiguous())
-        assert torch.allclose(obs[:, 13:16], ((f[O.F_WP0:O.F_WP0 + 3] - f[0:3]) / 2).T, atol=1e-6)
+        tp = env.ee_position().T if vehicle == "hexa_arm" else f[0:3]          # the arm's task measures from the tool point
+        assert torch.allclose(obs[:, 13:16], ((f[O.F_WP0:O.F_WP0 + 3] - tp) / 2).T, atol=1e-6)
+        if vehicle == "hexa_arm":
+            assert torch.allclose(obs[:, 26:29], ((tp - f[0:3]) / 0.5).T, atol=2e-6) and float((tp - f[0:3]).norm(dim=0).max()) < 0.4
         st = env.stats()
-        assert st["episodes"] == ndone and st["steps"] == n * T
+        assert st["episodes"] == ndone and st["steps"] == n * T and ndone > n // 10
         assert st["terminated"] + st["truncated"] == st["episodes"]
         assert st["crashed"] + st["oob"] + st["success"] + st["nonfinite"] >= st["terminated"]
         runs.append((f.clone(), i.clone(), obs.clone(), st))
@@ -633,3 +644,33 @@ def test_reset_rng_helper_wave_is_bit_identical(amd, kw, n):
     assert torch.equal(f0, f1) and torch.equal(i0, i1) and s0 == s1 and s0["episodes"] > n // 5
     for a, b in zip(r0, r1):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("vehicle", ["quad", "hexa", "hexa_arm"])
+@pytest.mark.parametrize("n", [300, 4096])
+def test_every_accepted_block_size_is_bit_identical(amd, vehicle, n):
+    """amenv_config.block_size 64 / 128 / 256 (the divisors of the 256-lane allocation granule; 192 is refused: tests/test_capi_cpu.py)
+    on the one-lane-per-env kernel: identical trajectories, outputs and totals; n = 300 leaves a ragged last workgroup."""
+    torch = _torch()
+    ad = 7 if vehicle == "hexa_arm" else 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = torch.randn(120, n, ad, device="cuda", generator=g) * 0.2
+    acts[..., 0] += 1.0
+    acts[:, ::4, 0] = 0.1
+    acts = acts.clamp(-1, 2)
+    outs = []
+    for bs in (64, 128, 256):
+        env = amd.GpuWaypointEnv(n, seed=5, vehicle=vehicle, block_size=bs, kernel="lane", max_episode_steps=70)
+        assert f"block={bs}" in env.kernel_name
+        env.reset()
+        rec = []
+        for t in range(120):
+            obs, rew, done, info = env.step(acts[t].clone())
+            rec.append((obs.clone(), rew.clone(), done.clone(), info.clone()))
+        f, i = env.get_state()
+        outs.append((rec, f.clone(), i.clone(), env.stats()))
+        env.close()
+    for rec, f, i, st in outs[1:]:
+        assert torch.equal(f, outs[0][1]) and torch.equal(i, outs[0][2]) and st == outs[0][3] and st["episodes"] > n // 8
+        for a, b in zip(rec, outs[0][0]):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))

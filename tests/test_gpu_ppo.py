@@ -352,3 +352,66 @@ def test_training_script_runs(tmp_path):
     assert "Mean reward:" in r.stdout and os.path.exists(out + ".zip")
     pol = ActorCritic.from_sb3(out + ".zip")
     assert pol.num_parameters() == 30537
+
+
+@pytest.mark.parametrize("vehicle", ["quad", "hexa_arm"])
+def test_ppo_at_config5_batch_32768_envs(vehicle):
+    """BASELINE configs[4]: PPO rollout + update at 32768 envs on ONE GPU (the per-GPU share of the 8-GPU job).  Short rollouts, 2
+    iterations; the invariants asserted at 512..2048 envs hold at this size: buffer consistent with policy and env, GAE equal to the
+    SB3 restatement, finite losses, parameters move, and the HIP-graph update equals the eager update on the same rollout."""
+    from oracle import oracle as O
+    n, T = 32768, 8
+    out = []
+    for use_graph in (False, True):
+        env = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=17, max_episode_steps=6)     # truncations inside the short rollout
+        assert env.num_envs == n
+        algo = PPO(env, n_steps=T, batch_size=65536, n_epochs=2, seed=9, use_graph=use_graph)
+        with torch.no_grad():
+            algo.policy.log_std.data.fill_(-1.0)
+        b = algo.collect_rollouts()
+        N = T * n
+        with torch.no_grad():
+            values, logp, _ = algo.policy.evaluate_actions(b.obs[:T].reshape(N, -1), b.actions.reshape(N, -1))
+        assert float((logp - b.logp.reshape(N)).abs().max()) < 5e-4
+        assert float((values - b.values.reshape(N)).abs().max()) < 1e-3 * max(1.0, float(values.abs().max()))
+        d = b.dones.bool()
+        assert int(d[6].sum()) > n // 2                                               # the 7th step is past the 6-step limit
+        if not use_graph:
+            r, v, dn, lv = (x.cpu().numpy() for x in (b.rewards, b.values, b.dones, b.last_values))
+            adv_ref, _ = O.gae_reference(r, v, dn, lv, 0.995, 0.9)
+            assert (np.abs(b.advantages.cpu().numpy() - adv_ref) / (1.0 + gae_magnitude(r, v, dn, lv))).max() < 1e-6
+        p0 = algo.policy.flat_param.detach().clone()
+        rec = algo.train()
+        assert all(math.isfinite(x) for x in rec.values()) and rec["grad_norm"] > 0
+        assert float((algo.policy.flat_param.detach() - p0).abs().max()) > 1e-5
+        out.append((algo.policy.flat_param.detach().clone(), rec, algo._step._graphs is not None))
+        algo.learn(N)                                                                  # one more full iteration through learn()
+        assert algo.num_timesteps == 2 * N and math.isfinite(algo.log[-1]["value_loss"])
+        env.close()
+    (pa, ra, ga), (pb, rb, gb) = out
+    assert not ga and gb
+    assert float((pa - pb).abs().max()) < 2e-5 and abs(ra["value_loss"] - rb["value_loss"]) <= 1e-4 * abs(ra["value_loss"])
+
+
+def test_checkpoint_cadence_and_full_resume(tmp_path):
+    """CheckpointCallback(save_freq, save_path, name_prefix) + PPO.load(...) then learn (v2/rl_train.py:14-18,33-35,56): checkpoints land
+    at the cadence, and a resumed run restores weights, Adam moments, step count, learning rate and the timestep counter."""
+    env = amd.GpuWaypointEnv(512, seed=1)
+    algo = PPO(env, n_steps=32, batch_size=4096, n_epochs=2, seed=2, learning_rate=3e-4)
+    per_iter = 32 * 512
+    algo.learn(5 * per_iter, save_freq=2 * per_iter, save_path=str(tmp_path), name_prefix="ppo_model")
+    files = sorted(os.listdir(tmp_path))
+    assert files == [f"ppo_model_{2 * per_iter}_steps.zip", f"ppo_model_{4 * per_iter}_steps.zip"], files
+    final = algo.save(os.path.join(tmp_path, "final"))
+    st = algo.optimizer.state[algo._leaf]
+    env2 = amd.GpuWaypointEnv(512, seed=1)
+    res = PPO(env2, n_steps=32, batch_size=4096, n_epochs=2, seed=2)            # default lr 2e-4: must be overwritten by the checkpoint
+    res.load(final)
+    st2 = res.optimizer.state[res._leaf]
+    assert torch.equal(res.policy.flat_param.detach(), algo.policy.flat_param.detach())
+    assert float(st2["step"]) == float(st["step"]) == 5 * 2 * 4 and torch.equal(st2["exp_avg"], st["exp_avg"]) and torch.equal(st2["exp_avg_sq"], st["exp_avg_sq"])
+    assert res.optimizer.param_groups[0]["lr"] == 3e-4 and res.num_timesteps == 5 * per_iter and res._draw == algo._draw
+    res.learn(per_iter)
+    assert res.num_timesteps == 6 * per_iter and all(math.isfinite(v) for v in res.log[-1].values())
+    assert float(res.optimizer.state[res._leaf]["step"]) == 6 * 2 * 4
+    env.close(); env2.close()

@@ -16,12 +16,13 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "auto"
 
 
 def collect(counter, envs, vehicle, outdir):
     d = os.path.join(outdir, f"pmc_{counter}_{envs}")
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_step.py"),
-           "--envs", str(envs), "--steps", "120", "--vehicle", vehicle, "--calibrate"]
+           "--envs", str(envs), "--steps", "120", "--vehicle", vehicle, "--calibrate", "--kernel", KERNEL]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300)
     acc = collections.defaultdict(list)
@@ -31,17 +32,30 @@ def collect(counter, envs, vehicle, outdir):
                 acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
     step = [v for k, v in acc.items() if "step_kernel" in k]
     mean = lambda xs: sum(xs) / len(xs)
-    # the 256 MiB calibration copy is by far the largest non-step dispatch
-    cal = max((mean(v) for k, v in acc.items() if "step_kernel" not in k), default=None)
+    # the calibration dispatch is selected BY NAME: torch's elementwise kernel of `torch.mul(src, 1.0, out=dst)` over 256 MiB (pmc_step.py);
+    # among the elementwise dispatches of the run it is the only one of that size
+    cal = max((max(v) for k, v in acc.items() if "elementwise_kernel" in k), default=None)
     return mean(step[0][20:]), cal
+
+
+CAL_KIB = 256 * 1024   # the calibration copy reads and writes 256 MiB
+
+
+def calibration_ok(f_cal, w_cal):
+    """FETCH_SIZE must read half the copy (the gfx950 16-B/lane correction), WRITE_SIZE all of it, both within 5 %."""
+    return f_cal is not None and w_cal is not None and abs(2.0 * f_cal / CAL_KIB - 1.0) < 0.05 and abs(w_cal / CAL_KIB - 1.0) < 0.05
+
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", nargs="+", type=int, default=[4096])
     ap.add_argument("--vehicle", default="hexa")
+    ap.add_argument("--kernel", default="auto")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
     a = ap.parse_args()
+    global KERNEL
+    KERNEL = a.kernel
     a.out = os.path.abspath(a.out)   # rocprofv3 runs with cwd=/tmp
     os.makedirs(a.out, exist_ok=True)
     path = os.path.join(a.out, "traffic.json")
@@ -51,6 +65,10 @@ def main():
         w_kib, w_cal = collect("WRITE_SIZE", n, a.vehicle, a.out)
         fetch = 2.0 * f_kib * 1024.0   # gfx950 correction for 16-B/lane coalesced reads
         write = w_kib * 1024.0
+        if not calibration_ok(f_cal, w_cal):   # never record a traffic figure whose unit / correction check failed
+            print(f"N={n}: calibration copy reads fetch {f_cal} KiB (want ~{CAL_KIB // 2}) write {w_cal} KiB (want ~{CAL_KIB}): entry NOT written", flush=True)
+            res.pop(f"{a.vehicle}_{n}_f32", None)
+            continue
         res[f"{a.vehicle}_{n}_f32"] = dict(fetch_size_kib_raw=f_kib, write_size_kib_raw=w_kib, fetch_bytes_per_launch=fetch,
                                           write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
                                           calibration_copy_256MiB=dict(fetch_kib_raw=f_cal, write_kib_raw=w_cal))
