@@ -373,7 +373,7 @@ def extras(args, amd, torch, env, ring, n, device):
         e2.stats(reset=True)
         ms = timed(lambda: [g.replay() for _ in range(S // GRAPH_CHUNK)], 5)
         st = e2.stats()
-        prot[tag] = {"env_steps_per_s": S * n / (ms * 1e-3), "us_per_step": ms * 1e3 / S, "episodes_per_1000_env_steps": 1000.0 * st["episodes"] / max(1, st["steps"])}
+        prot[tag] = {"env_steps_per_s": S * n / (ms * 1e-3), "us_per_step": ms * 1e3 / S, "episodes_per_1000_env_steps": 1000.0 * st["episodes"] / (5.0 * S * n)}
         e2.close()
     # C: policy in the loop (the reference's architecture, random-init weights of this vehicle's obs / action dims: no checkpoint exists for the arm)
     pol = amd.ActorCritic(env.obs_dim, env.act_dim).to(device)
@@ -391,8 +391,10 @@ def extras(args, amd, torch, env, ring, n, device):
 
     closed_loop(8)
     ms = timed(lambda: closed_loop(S // 8), 5)
+    with torch.no_grad():
+        fused = bool(pol.fused_ok(obs))
     prot["C_policy_closed_loop"] = {"env_steps_per_s": (S // 8) * n / (ms * 1e-3), "us_per_step": ms * 1e3 / (S // 8),
-                                    "fused_policy_kernel": bool(pol.fused_ok(obs)), "weights": "random init (reference architecture 128-64-64 tanh)"}
+                                    "fused_policy_kernel": fused, "weights": "random init (reference architecture 128-64-64 tanh)"}
     e3.close()
     ex["survey_8d"] = {"steps": S, "warmup": GRAPH_CHUNK, "repeats": 5, "statistic": "median", **prot}
     return ex

@@ -471,9 +471,31 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
   T y[19] = {e.px, e.py, e.pz, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz, e.th[0], e.th[1], e.th[2], e.thd[0], e.thd[1], e.thd[2]};
   const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
   int it = 0;
+#ifndef AMENV_F64_ARM_UNROLLED
+  if constexpr (sizeof(T) == 8 && ROLE == ARM_ROLE_ALL) {
+    // fp64 logic-check build: the four RK4 stages as a LOOP around ONE copy of the RHS (stage weights from the stage index).  Four
+    // inlined fp64 RHS bodies need > 512 registers; that build spills 110 VGPRs to scratch (332 B per lane, next to 324 spilled SGPRs)
+    // and returned garbage on gfx950 / ROCm 7.2 (joint rates of 1e15 after one step: tools/micro/f64_arm_unrolled_repro.py rebuilds it with
+    // -DAMENV_F64_ARM_UNROLLED).  The loop needs 256 VGPRs + 202 AGPRs and no scratch.  Same expressions per stage as the unrolled form.
+    do {
+      T k[19], acc[19], s[19];
+#pragma unroll
+      for (int i = 0; i < 19; i++) { acc[i] = T(0); s[i] = y[i]; }
+#pragma unroll 1
+      for (int st = 0; st < 4; st++) {
+        arm_rhs<AX, ROLE, X, 0>(P, A, s, F, M, cmd, k, x, y, hh, static_cast<ChainState<T>*>(nullptr));
+        const T wgt = (st == 0 || st == 3) ? T(1) : T(2);
+        const T cn = st == 2 ? h : hh;
+#pragma unroll
+        for (int i = 0; i < 19; i++) { acc[i] = fma_(wgt, k[i], acc[i]); s[i] = fma_(cn, k[i], y[i]); }
+      }
+#pragma unroll
+      for (int i = 0; i < 19; i++) y[i] = fma_(h6, acc[i], y[i]);
+    } while (++it < P.substeps);
+  } else
+#endif
   do {
-    // RK4 with a running weighted sum (acc = k1 + 2 k2 + 2 k3 + k4): four 19-vectors live instead of six -- the fp64
-    // build of this kernel otherwise needs more than the 512 registers a wave can have
+    // RK4 with a running weighted sum (acc = k1 + 2 k2 + 2 k3 + k4): four 19-vectors live instead of six
     T k[19], acc[19], s[19];
     [[maybe_unused]] ChainState<T> cs;   // helper wave: chain behind joint 2, from its look-ahead to the next RHS
     arm_rhs<AX, ROLE, X, 0, IW>(P, A, y, F, M, cmd, k, x, y, hh, &cs, idle);

@@ -262,9 +262,6 @@ const char* validate(const amenv_config* c) {
   if (c->vehicle.n_joints != 0 && c->vehicle.n_joints != 3) return "n_joints must be 0 or 3";
   if (c->vehicle.n_joints == 3 && (c->vehicle.n_rotors != 6 || c->task.num_waypoints != 1 || is_v1(c)))
     return "the arm vehicle is built for the 6-rotor airframe, the v2 task and 1 waypoint (BASELINE config 3)";
-  if (c->vehicle.n_joints == 3 && c->dtype == AMENV_F64)
-    return "no fp64 build of the arm kernel: four inlined fp64 multibody RHS evaluations exceed the 512 registers of a wavefront and "
-           "the spilled build computes garbage on gfx950/ROCm 7.2 (DESIGN.md); the fp32 arm kernel is checked against the fp64 oracle";
   if (c->task.variant != AMENV_TASK_V2_SCALED20 && !is_v1(c)) return "unknown task variant";
   if (is_v1(c) && c->task.num_waypoints > 2) return "v1 tasks draw 1..2 waypoints per episode: num_waypoints (storage bound) must be 1 or 2";
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
@@ -338,9 +335,7 @@ hipError_t dispatch_k(const amenv& e, const StepIO& io, int T_steps, hipStream_t
 template <typename T>
 hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed = false) {
   const int nr = e.cfg.vehicle.n_rotors;
-  if constexpr (sizeof(T) == 4) {   // BASELINE config 3 (fp32 only, see validate())
-    if (e.cfg.vehicle.n_joints == 3) return launch_step<T, 6, 1, VAR_V2, 3>(e, io, T_steps, s, timed);
-  }
+  if (e.cfg.vehicle.n_joints == 3) return launch_step<T, 6, 1, VAR_V2, 3>(e, io, T_steps, s, timed);   // BASELINE config 3
   if (nr == 4) return dispatch_k<T, 4>(e, io, T_steps, s, timed);
   if (nr == 6) return dispatch_k<T, 6>(e, io, T_steps, s, timed);
   return dispatch_k<T, AMENV_MAX_ROTORS>(e, io, T_steps, s, timed);
@@ -366,7 +361,7 @@ hipError_t launch_observe(const amenv& e, float* obs, float* ee, hipStream_t s) 
 template <typename T>
 hipError_t launch_transpose(const amenv& e, void* f, int32_t* i, int to_api, hipStream_t s) {
   const int bs = 256, n = e.cfg.num_envs;
-  hipLaunchKernelGGL((transpose_state_kernel<T>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, e.nf, e.tile_bytes, e.blob, (T*)f, i, to_api);
+  hipLaunchKernelGGL((transpose_state_kernel<T>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, e.nf, e.cfg.task.num_waypoints, e.cfg.vehicle.n_joints, e.tile_bytes, e.blob, (T*)f, i, to_api);
   return hipGetLastError();
 }
 
@@ -459,7 +454,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // tiles are allocated in multiples of 4 (= 256 lanes, the largest workgroup): every launch geometry stays inside the blob and
   // every padding lane holds a valid environment (initialised below), so kernels never need a per-lane bounds branch on the state
   e->n_tiles = int((n + 255) / 256) * 4;
-  e->tile_bytes = tile_bytes_for(e->nf, int(ts));
+  e->tile_bytes = tile_bytes_for(cfg->task.num_waypoints, cfg->vehicle.n_joints, int(ts));
   e->blob_bytes = size_t(e->n_tiles) * e->tile_bytes;
   // latency regime (few waves per CU): one wave per workgroup spreads the waves over more CUs;
   // throughput regime: 256-thread workgroups

@@ -1,18 +1,19 @@
 // amenv_kernels.hpp -- gfx950 kernels of the batched waypoint environment.
 //
 // Data layout in HBM (DESIGN.md "Layout")
-//   state blob : tiles of 64 environments (one wavefront each), tile t at byte t * tile_bytes:
-//                  [int4 plane ][64 lanes] {step, counter, flags, episode}          offset 0, 16 B/lane
-//                  [G float4 groups][64 lanes] {field 4g .. 4g+3} of type T          offset 1024 + g*64*4*sizeof(T)
-//                Field order = enum amenv_float_field: the 13 rigid-body states + final_yaw + last_distance +
-//                ep_return fill groups 0..3 exactly; waypoints follow.  Every access is 16 B per lane
-//                (fp32): a wave moves 1 KiB per instruction, fully coalesced, field-group offsets are
-//                instruction immediates.  fp32/K=1: 6 loads + 5 stores per env-step instead of 22 + 18 dwords.
-//   actions    : f32 [N][4]   one float4 per lane, coalesced
-//   obs        : f32 [N][20]  row-major for the policy MLP: rows are staged through LDS and written
-//                             as contiguous 1-KiB float4 wave stores
-// One lane owns one environment for the whole step: load -> mixer -> RK4 -> reward -> state machine
-// -> (masked) auto-reset -> observation, a single launch per control step.
+//   state blob : tiles of 64 environments, tile t at byte t * tile_bytes:
+//                  [int4 plane ][64 envs] {step, counter, flags, episode}             offset 0, 16 B/env
+//                  [G float4 groups][64 envs], group g at offset 1024 + g*64*4*sizeof(T); each group is ONE vector quantity
+//                  (+ one per-env scalar in its 4th slot), so that both kernel families read it with one instruction:
+//                    g0 {px,py,pz, final_yaw}  g1 {vx,vy,vz, last_distance}  g2 {qw,qx,qy,qz}  g3 {wx,wy,wz, ep_return}
+//                    g4.. {waypoint k: x,y,z,-} (K groups)   then with an arm {th0,th1,th2,-} {thd0,thd1,thd2,-}
+//                * one-lane-per-env kernels: a lane moves its env's group as 16 B -> a wave moves 1 KiB per instruction, coalesced;
+//                * lane-team kernels (4 or 16 lanes per env): lane c of a team moves component c as a dword: the team's lanes cover
+//                  the 16 B, consecutive envs are contiguous, the per-lane offset is the same for every group.
+//                The public amenv_get/set_state view stays [field][N] (enum amenv_float_field); field_slot() is the map.
+//   actions    : f32 [N][A]   one float4 per lane (A = 4), coalesced
+//   obs        : f32 [N][OD]  row-major for the policy MLP: rows are staged through LDS and written as contiguous 1-KiB wave stores
+//                             (lane-team kernels write their components directly)
 #pragma once
 #include "amenv_model.hpp"
 #include "amenv_arm.hpp"
@@ -29,9 +30,24 @@ constexpr uint32_t kIntBytes = 64 * 4 * sizeof(int32_t);  // 1024: one int4 per 
 
 template <typename T> struct alignas(4 * sizeof(T)) Vec4 { T a, b, c, d; };
 
-__host__ __device__ inline int n_groups_for(int n_float_fields) { return (n_float_fields + 3) / 4; }
-__host__ __device__ inline uint32_t tile_bytes_for(int n_float_fields, int tsize) {
-  return kIntBytes + uint32_t(n_groups_for(n_float_fields)) * 64u * 4u * uint32_t(tsize);
+// groups of a configuration: 4 (rigid-body state + the three per-env scalars) + one per waypoint + two with an arm
+__host__ __device__ inline int n_groups_for(int K, int nj) { return 4 + K + (nj > 0 ? 2 : 0); }
+__host__ __device__ inline uint32_t tile_bytes_for(int K, int nj, int tsize) {
+  return kIntBytes + uint32_t(n_groups_for(K, nj)) * 64u * 4u * uint32_t(tsize);
+}
+// public field index (enum amenv_float_field; joints after the waypoints) -> 4 * group + slot in the tile
+__host__ __device__ inline int field_slot(int f, int K, int nj) {
+  if (f < 3) return f;                                  // position           g0.0-2
+  if (f < 6) return 4 + (f - 3);                        // velocity           g1.0-2
+  if (f < 10) return 8 + (f - 6);                       // quaternion         g2
+  if (f < 13) return 12 + (f - 10);                     // body rates         g3.0-2
+  if (f == AMENV_F_FINAL_YAW) return 3;                 //                    g0.3
+  if (f == AMENV_F_LAST_DISTANCE) return 7;             //                    g1.3
+  if (f == AMENV_F_EP_RETURN) return 15;                //                    g3.3
+  const int w = f - AMENV_F_WP0;
+  if (w < 3 * K) return 4 * (4 + w / 3) + w % 3;        // waypoint k         g(4+k).0-2
+  const int j = w - 3 * K, d = nj > 0 ? nj : 1;         // joints: angles then rates
+  return 4 * (4 + K + j / d) + j % d;
 }
 
 // byte address of the tile that holds env i
@@ -43,67 +59,61 @@ template <typename T> __device__ __forceinline__ Vec4<T>* gptr(char* tile, int l
 }
 __device__ __forceinline__ int4* iptr4(char* tile, int lane) { return reinterpret_cast<int4*>(tile) + lane; }
 // scalar views (transposes, lazy episode load)
-template <typename T> __device__ __forceinline__ T* fptr(char* tile, int lane, int field) {
-  return reinterpret_cast<T*>(gptr<T>(tile, lane, field >> 2)) + (field & 3);
+template <typename T> __device__ __forceinline__ T* fptr(char* tile, int lane, int field, int K, int nj) {
+  const int gs = field_slot(field, K, nj);
+  return reinterpret_cast<T*>(gptr<T>(tile, lane, gs >> 2)) + (gs & 3);
 }
 __device__ __forceinline__ int32_t* iptr(char* tile, int lane, int field) { return reinterpret_cast<int32_t*>(iptr4(tile, lane)) + field; }
 
-static_assert(AMENV_F_WP0 == 16 && AMENV_F_FINAL_YAW == 13 && AMENV_F_LAST_DISTANCE == 14 && AMENV_F_EP_RETURN == 15, "groups 0..3 = 16 hot fields");
+static_assert(AMENV_F_WP0 == 16 && AMENV_F_FINAL_YAW == 13 && AMENV_F_LAST_DISTANCE == 14 && AMENV_F_EP_RETURN == 15, "field_slot() assumes this field order");
 
 template <typename T, int KW, int NJ = 0>
 __device__ __forceinline__ void load_env(int K, const char* tile_c, int lane, Env<T, KW>& e) {
   char* tile = const_cast<char*>(tile_c);
   const Vec4<T> g0 = *gptr<T>(tile, lane, 0), g1 = *gptr<T>(tile, lane, 1), g2 = *gptr<T>(tile, lane, 2), g3 = *gptr<T>(tile, lane, 3);
   const int4 iv = *iptr4(tile, lane);
-  e.px = g0.a; e.py = g0.b; e.pz = g0.c; e.vx = g0.d;
-  e.vy = g1.a; e.vz = g1.b; e.qw = g1.c; e.qx = g1.d;
-  e.qy = g2.a; e.qz = g2.b; e.wx = g2.c; e.wy = g2.d;
-  e.wz = g3.a; e.final_yaw = g3.b; e.last_distance = g3.c; e.ep_return = g3.d;
-  // waypoint k = fields 16+3k .. 18+3k: contiguous floats starting in group 4
-  // (with an arm the 2*NJ joint fields follow the waypoints; NJ > 0 is only instantiated with KW = K)
-  constexpr int NG = (3 * KW + 2 * NJ + 3) / 4;
-  T w[NG * 4];
+  e.px = g0.a; e.py = g0.b; e.pz = g0.c; e.final_yaw = g0.d;
+  e.vx = g1.a; e.vy = g1.b; e.vz = g1.c; e.last_distance = g1.d;
+  e.qw = g2.a; e.qx = g2.b; e.qy = g2.c; e.qz = g2.d;
+  e.wx = g3.a; e.wy = g3.b; e.wz = g3.c; e.ep_return = g3.d;
 #pragma unroll
-  for (int g = 0; g < NG; g++) {
+  for (int k = 0; k < KW; k++) {   // one group per waypoint
     Vec4<T> v{T(0), T(0), T(0), T(0)};
-    if (NJ > 0 || 3 * K > 4 * g) v = *gptr<T>(tile, lane, 4 + g);
-    w[4 * g] = v.a; w[4 * g + 1] = v.b; w[4 * g + 2] = v.c; w[4 * g + 3] = v.d;
+    if (k < K) v = *gptr<T>(tile, lane, 4 + k);
+    e.wp[k][0] = v.a; e.wp[k][1] = v.b; e.wp[k][2] = v.c;
   }
 #pragma unroll
-  for (int k = 0; k < KW; k++) { e.wp[k][0] = w[3 * k]; e.wp[k][1] = w[3 * k + 1]; e.wp[k][2] = w[3 * k + 2]; }
-#pragma unroll
-  for (int k = 0; k < AMENV_MAX_JOINTS; k++) {
-    e.th[k] = k < NJ ? w[3 * KW + k] : T(0);
-    e.thd[k] = k < NJ ? w[3 * KW + NJ + k] : T(0);
+  for (int k = 0; k < AMENV_MAX_JOINTS; k++) { e.th[k] = T(0); e.thd[k] = T(0); }
+  if constexpr (NJ > 0) {          // joint angles, joint rates (NJ > 0 is only instantiated with KW = K)
+    const Vec4<T> a = *gptr<T>(tile, lane, 4 + KW), r = *gptr<T>(tile, lane, 5 + KW);
+    e.th[0] = a.a; e.th[1] = a.b; e.th[2] = a.c;
+    e.thd[0] = r.a; e.thd[1] = r.b; e.thd[2] = r.c;
   }
+  e.eox = e.eoy = e.eoz = T(0);
   e.step = iv.x; e.counter = iv.y; e.flags = iv.z; e.episode = iv.w;
 }
 
-// per-step store: groups 0..3 + the int4 (final_yaw and episode are rewritten with their unchanged values)
-template <typename T, int KW>
+// per-step store: groups 0..3 + the int4 (final_yaw and episode are rewritten with their unchanged values); with an arm the two
+// joint groups as well (the waypoint group is not rewritten)
+template <typename T, int KW, int NJ = 0>
 __device__ __forceinline__ void store_env_step(char* tile, int lane, const Env<T, KW>& e) {
-  *gptr<T>(tile, lane, 0) = Vec4<T>{e.px, e.py, e.pz, e.vx};
-  *gptr<T>(tile, lane, 1) = Vec4<T>{e.vy, e.vz, e.qw, e.qx};
-  *gptr<T>(tile, lane, 2) = Vec4<T>{e.qy, e.qz, e.wx, e.wy};
-  *gptr<T>(tile, lane, 3) = Vec4<T>{e.wz, e.final_yaw, e.last_distance, e.ep_return};
+  *gptr<T>(tile, lane, 0) = Vec4<T>{e.px, e.py, e.pz, e.final_yaw};
+  *gptr<T>(tile, lane, 1) = Vec4<T>{e.vx, e.vy, e.vz, e.last_distance};
+  *gptr<T>(tile, lane, 2) = Vec4<T>{e.qw, e.qx, e.qy, e.qz};
+  *gptr<T>(tile, lane, 3) = Vec4<T>{e.wx, e.wy, e.wz, e.ep_return};
+  if constexpr (NJ > 0) {
+    *gptr<T>(tile, lane, 4 + KW) = Vec4<T>{e.th[0], e.th[1], e.th[2], T(0)};
+    *gptr<T>(tile, lane, 5 + KW) = Vec4<T>{e.thd[0], e.thd[1], e.thd[2], T(0)};
+  }
   *iptr4(tile, lane) = make_int4(e.step, e.counter, e.flags, e.episode);
 }
 
 // per-episode constants (waypoints), written only by lanes that were reset
-// (with an arm the joint fields share these groups and change every step: then this runs every step)
-template <typename T, int KW, int NJ = 0>
+template <typename T, int KW>
 __device__ __forceinline__ void store_env_episode(int K, char* tile, int lane, const Env<T, KW>& e) {
-  constexpr int NG = (3 * KW + 2 * NJ + 3) / 4;
-  T w[NG * 4];
 #pragma unroll
-  for (int j = 0; j < NG * 4; j++) w[j] = T(0);
-#pragma unroll
-  for (int k = 0; k < KW; k++) { w[3 * k] = e.wp[k][0]; w[3 * k + 1] = e.wp[k][1]; w[3 * k + 2] = e.wp[k][2]; }
-#pragma unroll
-  for (int k = 0; k < NJ; k++) { w[3 * KW + k] = e.th[k]; w[3 * KW + NJ + k] = e.thd[k]; }
-#pragma unroll
-  for (int g = 0; g < NG; g++)
-    if (NJ > 0 || 3 * K > 4 * g) *gptr<T>(tile, lane, 4 + g) = Vec4<T>{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
+  for (int k = 0; k < KW; k++)
+    if (k < K) *gptr<T>(tile, lane, 4 + k) = Vec4<T>{e.wp[k][0], e.wp[k][1], e.wp[k][2], T(0)};
 }
 
 // Stage this lane's observation row in LDS.  OD = 20 (80-B rows): five ds_write_b128, the 8 lanes of a group land on banks
@@ -385,8 +395,8 @@ __global__ __launch_bounds__(256) AMENV_STEP_WAVES_ATTR void step_kernel(void* _
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   AMENV_STAMP(3);          // dynamics + task + obs computed
   accumulate_stats(io.stats, int((blockIdx.x * blockDim.x + threadIdx.x) >> 6), bits, is_done, ep_len, ep_ret);
-  store_env_step<T, KW>(tile, lane, e);
-  if (NJ > 0 || was_reset) store_env_episode<T, KW, NJ>(K, tile, lane, e);
+  store_env_step<T, KW, NJ>(tile, lane, e);
+  if (was_reset) store_env_episode<T, KW>(K, tile, lane, e);
   if (active) {
     reinterpret_cast<T*>(io.reward)[i] = reward;
     io.done[i] = is_done ? 1 : 0;
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(192) void step_kernel_pw(void* __restrict__ blob, u
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
   store_env_step<T, KW>(tile, lane, e);
-  if (was_reset) store_env_episode<T, KW, 0>(K, tile, lane, e);
+  if (was_reset) store_env_episode<T, KW>(K, tile, lane, e);
   if (active) {
     reinterpret_cast<T*>(io.reward)[i] = reward;
     io.done[i] = is_done ? 1 : 0;
@@ -582,8 +592,8 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
                                                                         ep_len, ep_ret, x);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
-  store_env_step<T, KW>(tile, lane, e);
-  store_env_episode<T, KW, NJ>(1, tile, lane, e);
+  store_env_step<T, KW, NJ>(tile, lane, e);
+  if (was_reset) store_env_episode<T, KW>(1, tile, lane, e);
   if (active) {
     reinterpret_cast<T*>(io.reward)[i] = reward;
     io.done[i] = is_done ? 1 : 0;
@@ -659,8 +669,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
       __syncthreads();
     }
   }
-  store_env_step<T, KW>(tile, lane, e);
-  if (NJ > 0 || any_reset) store_env_episode<T, KW, NJ>(K, tile, lane, e);
+  store_env_step<T, KW, NJ>(tile, lane, e);
+  if (any_reset) store_env_episode<T, KW>(K, tile, lane, e);
 }
 
 // WaypointQuadEnv.reset for masked envs (mask null = all) + observation of every env.
@@ -670,8 +680,8 @@ template <typename T, int KW>
 __device__ __forceinline__ void joints_and_tool(const ArmParams<T>& A, int K, int nj, char* tile, int lane, Env<T, KW>& e) {
 #pragma unroll
   for (int j = 0; j < AMENV_MAX_JOINTS; j++) {
-    e.th[j] = j < nj ? *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j) : T(0);
-    e.thd[j] = j < nj ? *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + nj + j) : T(0);
+    e.th[j] = j < nj ? *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j, K, nj) : T(0);
+    e.thd[j] = j < nj ? *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + nj + j, K, nj) : T(0);
   }
   e.eox = e.eoy = e.eoz = T(0);
   if (nj > 0) update_tool_offset<T, KW, false>(A, e);
@@ -694,7 +704,7 @@ __global__ void reset_kernel(int n, int n_pad, int K, int variant, int nj, int e
     reset_env<T, AMENV_MAX_WAYPOINTS>(C, K, v1, e, C.gid0 + i);
     store_env_step<T, AMENV_MAX_WAYPOINTS>(tile, lane, e);
     store_env_episode<T, AMENV_MAX_WAYPOINTS>(K, tile, lane, e);
-    for (int j = 0; j < 2 * nj; j++) *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j) = T(0);   // arm at home, at rest
+    for (int j = 0; j < 2 * nj; j++) *fptr<T>(tile, lane, AMENV_F_WP0 + 3 * K + j, K, nj) = T(0);   // arm at home, at rest
   }
   if (obs && active) {
     float o[kObsDimMax];
@@ -741,7 +751,7 @@ __global__ void ee_position_kernel(int n, int K, int nj, uint32_t tile_bytes, co
 // amenv_get_state / amenv_set_state: the public struct-of-arrays view (fstate [NF][N] T, istate [4][N] i32)
 // <-> the internal tile layout.  to_api != 0: tiles -> SoA; else SoA -> tiles.
 template <typename T>
-__global__ void transpose_state_kernel(int n, int nf, uint32_t tile_bytes, void* __restrict__ blob, T* __restrict__ fapi,
+__global__ void transpose_state_kernel(int n, int nf, int K, int nj, uint32_t tile_bytes, void* __restrict__ blob, T* __restrict__ fapi,
                                        int32_t* __restrict__ iapi, int to_api) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -749,8 +759,8 @@ __global__ void transpose_state_kernel(int n, int nf, uint32_t tile_bytes, void*
   const int lane = threadIdx.x & 63;
   if (fapi)
     for (int f = 0; f < nf; f++) {
-      if (to_api) fapi[size_t(f) * n + i] = *fptr<T>(tile, lane, f);
-      else *fptr<T>(tile, lane, f) = fapi[size_t(f) * n + i];
+      if (to_api) fapi[size_t(f) * n + i] = *fptr<T>(tile, lane, f, K, nj);
+      else *fptr<T>(tile, lane, f, K, nj) = fapi[size_t(f) * n + i];
     }
   if (iapi)
     for (int f = 0; f < AMENV_I_NFIELDS; f++) {

@@ -36,10 +36,14 @@ def rand_actions(rng, n, scale=0.05):
     return a
 
 
-def test_arm_fp64_build_is_refused():
+def test_arm_fp64_build_exists_and_uses_the_lane_kernel():
+    """the fp64 logic-check build of the arm kernel (looped RK4: one copy of the RHS, no scratch)."""
     import rl_aerial_manipulator_amd as amd
-    with pytest.raises(amd.AmenvError, match="no fp64 build of the arm kernel"):
-        amd.GpuWaypointEnv(64, vehicle="hexa_arm", dtype="f64")
+    env = amd.GpuWaypointEnv(64, vehicle="hexa_arm", dtype="f64")
+    assert "step_kernel<double" in env.kernel_name and "arm3" in env.kernel_name
+    env.close()
+    with pytest.raises(amd.AmenvError, match="AMENV_KERNEL_HELPER"):
+        amd.GpuWaypointEnv(64, vehicle="hexa_arm", dtype="f64", kernel="helper")   # the two-wave kernel is fp32 only
 
 
 def test_arm_dims_and_reset():
@@ -61,7 +65,7 @@ def test_arm_dims_and_reset():
     env.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6)])   # fp32 kernel vs fp64 oracle: rounding level, far inside the 1e-5 gate
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("f64", 1e-12)])   # fp32 vs fp64 oracle: rounding level, far inside the 1e-5 gate; fp64 build: the logic gate
 def test_arm_closed_loop_vs_oracle(dtype, tol):
     """Teacher-forced per step (the oracle is re-seated on the GPU state each step), joints slewing, with resets."""
     import rl_aerial_manipulator_amd as amd
@@ -104,7 +108,7 @@ def test_arm_momentum_conservation_on_gpu():
     import torch
     import rl_aerial_manipulator_amd as amd
     n = 64
-    for dtype, tol in (("f32", 2e-4),):   # rounding-limited in fp32 (the fp64 statement of the model conserves to 5e-9: tests/test_arm_cpu.py)
+    for dtype, tol in (("f32", 2e-4), ("f64", 5e-9)):   # rounding-limited in fp32; fp64 build: integration error only (as the oracle, tests/test_arm_cpu.py)
         cfg = amd._lib.default_config("hexa_arm", n)
         cfg.vehicle.g = 0.0
         for r in range(8):

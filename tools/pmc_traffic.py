@@ -20,7 +20,9 @@ KERNEL = "auto"
 
 
 def collect(counter, envs, vehicle, outdir):
-    d = os.path.join(outdir, f"pmc_{counter}_{envs}")
+    d = os.path.join(outdir, f"pmc_{counter}_{vehicle}_{envs}")
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)   # a directory left by another run would mix its dispatches into this one's averages
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_step.py"),
            "--envs", str(envs), "--steps", "120", "--vehicle", vehicle, "--calibrate", "--kernel", KERNEL]
     env = dict(os.environ, TMPDIR="/tmp")
