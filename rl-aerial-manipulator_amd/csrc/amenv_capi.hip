@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "amenv_kernels.hpp"
+#include "amenv_team.hpp"
 #include "amenv_obsnorm.hpp"
 #include "amenv_policy.hpp"
 #include "amenv_train.hpp"
@@ -33,6 +34,8 @@ struct amenv {
   int block = 64;
   bool arm2w = false;              // hexacopter + z,x,x arm at small batches: two-wave step kernel (amenv_kernels.hpp)
   bool pwave = false;              // rigid vehicles at small batches: second wave per tile computes the reset RNG words (step_kernel_pw)
+  bool team = false;               // lane-team kernel (16 lanes per env): fp32 z,x,x-arm vehicle in the latency regime (amenv_team.hpp)
+  float* team_consts = nullptr;    // [kTeamConsts][16] per-lane constants of the team kernel
   uint64_t steps = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // amenv_step_timed only
   std::string err;
@@ -237,6 +240,59 @@ ArmParams<T> make_arm(const amenv& e) {
   return A;
 }
 
+// per-lane constant table of the team kernel: entry [k][4 * body + component] (amenv_team.hpp enum TeamConst)
+std::vector<float> team_const_table(const amenv_config& c) {
+  const amenv_vehicle& v = c.vehicle;
+  std::vector<float> t(size_t(kTeamConsts) * 16, 0.0f);
+  double m_links = 0;
+  for (int k = 0; k < 3; k++) m_links += v.link_mass[k];
+  const float inv_pi = float(0.31830988618379067154);
+  for (int b = 0; b < 4; b++)
+    for (int cc = 0; cc < 4; cc++) {
+      const int l = 4 * b + cc;
+      auto set = [&](int k, double x) { t[size_t(k) * 16 + l] = float(x); };
+      const double* I = b == 0 ? v.inertia : &v.link_inertia[9 * (b - 1)];
+      set(TC_I00, I[0]); set(TC_I01, I[1]); set(TC_I02, I[2]); set(TC_I11, I[4]); set(TC_I12, I[5]); set(TC_I22, I[8]);
+      for (int j = 0; j < 3; j++) set(TC_LCX + j, b == 0 ? 0.0 : v.link_com[3 * (b - 1) + j]);
+      set(TC_MASS, b == 0 ? v.mass - m_links : v.link_mass[b - 1]);
+      for (int k = 0; k < 3; k++) { set(TC_MK0 + k, b > k ? 1.0 : 0.0); set(TC_E0 + k, cc == k ? 1.0 : 0.0); }
+      for (int r = 0; r < v.n_rotors && r < 6; r++) { set(TC_ALLOC0 + r, v.alloc[r * 4 + cc]); set(TC_MIX0 + r, v.mix[cc * v.n_rotors + r]); }
+      const double sp[4] = {.5, -.5, .5, -.5}, sq[4] = {.5, -.5, -.5, .5}, sr[4] = {.5, .5, -.5, -.5};
+      set(TC_SP, sp[cc]); set(TC_SQ, sq[cc]); set(TC_SR, sr[cc]);
+      t[size_t(TC_ACT1) * 16 + l] = cc == 0 ? float(v.mass) : float(v.moment_scale);
+      t[size_t(TC_ACT2) * 16 + l] = cc == 0 ? float(v.g) : 1.0f;
+      if (cc < 3) {
+        const float lo = float(v.joint_limit[2 * cc]), hi = float(v.joint_limit[2 * cc + 1]);
+        t[size_t(TC_JHALF) * 16 + l] = 0.5f * (hi - lo); t[size_t(TC_JMID) * 16 + l] = 0.5f * (hi + lo);
+        set(TC_O0, v.joint_origin[cc]);
+      }
+      set(TC_GV, cc == 2 ? -v.g : 0.0); set(TC_GV1, cc == 1 ? -v.g : 0.0); set(TC_GV2, cc == 0 ? -v.g : 0.0);
+      const float oa[4] = {0.1f, 0.2f, 1.0f, 0.2f}, ob[4] = {0.5f, 0.0f, inv_pi, inv_pi}, oc[4] = {0.2f, 2.0f, 0.0f, 0.0f};
+      t[size_t(TC_OBS_A) * 16 + l] = oa[b]; t[size_t(TC_OBS_B) * 16 + l] = ob[b]; t[size_t(TC_OBS_C) * 16 + l] = oc[b];
+    }
+  return t;
+}
+
+TeamParams make_team(const amenv& e) {
+  const amenv_config& c = e.cfg;
+  const amenv_vehicle& v = c.vehicle;
+  TeamParams P;
+  std::memset(&P, 0, sizeof(P));
+  for (int j = 0; j < 3; j++) {
+    P.o1[j] = float(v.joint_origin[3 + j]); P.o2[j] = float(v.joint_origin[6 + j]); P.tool[j] = float(v.tool_offset[j]);
+    P.ee_home[j] = float(v.joint_origin[j] + v.joint_origin[3 + j] + v.joint_origin[6 + j] + v.tool_offset[j]);
+  }
+  P.kp = float(v.joint_kp); P.kd = float(v.joint_kd); P.amax = float(v.joint_acc_max);
+  P.mtot = float(v.mass); P.inv_mtot = float(1.0 / v.mass); P.g = float(v.g);
+  const int ns = c.task.rk4_substeps > 0 ? c.task.rk4_substeps : 1;
+  P.h = float(c.task.dt / ns); P.substeps = ns;
+  for (int r = 0; r < 6; r++) { P.tmin[r] = float(v.t_min[r]); P.tmax[r] = float(v.t_max[r]); }
+  P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit; P.flags = c.flags;
+  P.ee_task = c.task.ee_task == AMENV_EE_TASK_TOOL ? 1 : 0;
+  P.consts = e.team_consts;
+  return P;
+}
+
 ColdParams make_cold(const amenv& e) {
   const amenv_config& c = e.cfg;
   ColdParams C;
@@ -295,6 +351,15 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
   if constexpr (NJ == 3 && sizeof(T) == 4) {
+    if (T_steps == 0 && e.team) {    // 16 lanes per env, 4 envs per one-wave workgroup
+      const dim3 g2(e.n_tiles * 16), b2(64);
+      const TeamParams TP = make_team(e);
+      const float* act = reinterpret_cast<const float*>(io.actions);
+      if (timed) hipExtLaunchKernelGGL((step_kernel_team<NROT>), g2, b2, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done,
+                                       io.info, tl, P, C, TP);
+      else hipLaunchKernelGGL((step_kernel_team<NROT>), g2, b2, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, tl, P, C, TP);
+      return hipGetLastError();
+    }
     if (T_steps == 0 && e.arm2w) {   // one tile per 128-thread workgroup: main + helper wave
       const dim3 g2(e.n_tiles), b2(128);
       const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + (kArmXchgSlots + 12) * 64) * sizeof(float);   // obs rows | RK4 exchange | reset words
@@ -486,15 +551,28 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     amenv_destroy(e);
     return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_HELPER is built for fp32 z,x,x-arm vehicles and for rigid vehicles with block_size = 0");
   }
-  if (want == AMENV_KERNEL_TEAM) {
+  if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes)
+    e->team = want == AMENV_KERNEL_TEAM;
+  if (want == AMENV_KERNEL_TEAM && !e->team) {
     amenv_destroy(e);
-    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is not built for this configuration");
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is built for the fp32 6-rotor vehicle with the z,x,x arm");
+  }
+  if (e->team) {
+    e->arm2w = false;
+    const std::vector<float> tc = team_const_table(*cfg);
+    if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(float))) != hipSuccess ||
+        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
+      std::string msg = std::string("amenv_create: team constants: ") + hipGetErrorString(s);
+      amenv_destroy(e);
+      return fail(nullptr, AMENV_ERR_ALLOC, msg);
+    }
   }
   char buf[200];
   if (e->pwave) std::snprintf(buf, sizeof(buf), "step_kernel_pw<%s,NROT=%d,KW=%d,%s> (main wave + reset-RNG wave [+ observation wave] per 64-env tile)",
                               cfg->dtype == AMENV_F64 ? "double" : "float",
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
+  else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave)");
   else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
@@ -511,6 +589,7 @@ int amenv_destroy(amenv* e) {
     DeviceGuard g(e->device);
     if (e->blob) (void)hipFree(e->blob);
     if (e->stats) (void)hipFree(e->stats);
+    if (e->team_consts) (void)hipFree(e->team_consts);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
   }

@@ -65,13 +65,15 @@ def test_arm_dims_and_reset():
     env.close()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("f64", 1e-12)])   # fp32 vs fp64 oracle: rounding level, far inside the 1e-5 gate; fp64 build: the logic gate
-def test_arm_closed_loop_vs_oracle(dtype, tol):
+# fp32 vs fp64 oracle: rounding level, far inside the 1e-5 gate; fp64 build: the logic gate; "team" = the lane-team kernel (16 lanes per env)
+@pytest.mark.parametrize("dtype,tol,kernel", [("f32", 2e-6, "lane"), ("f32", 2e-6, "helper"), ("f32", 3e-6, "team"), ("f64", 1e-12, "lane")])
+def test_arm_closed_loop_vs_oracle(dtype, tol, kernel):
     """Teacher-forced per step (the oracle is re-seated on the GPU state each step), joints slewing, with resets."""
     import rl_aerial_manipulator_amd as amd
     n = 2048
     rng = np.random.RandomState(3)
-    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=9, dtype=dtype, max_episode_steps=120)
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=9, dtype=dtype, max_episode_steps=120, kernel=kernel)
+    assert {"lane": "step_kernel<", "helper": "arm2w", "team": "step_kernel_team"}[kernel] in env.kernel_name
     orc = orc_arm(n, seed=9)
     orc.cfg.task.max_episode_steps = 120
     env.reset()
@@ -108,7 +110,7 @@ def test_arm_momentum_conservation_on_gpu():
     import torch
     import rl_aerial_manipulator_amd as amd
     n = 64
-    for dtype, tol in (("f32", 2e-4), ("f64", 5e-9)):   # rounding-limited in fp32; fp64 build: integration error only (as the oracle, tests/test_arm_cpu.py)
+    for dtype, tol in (("f32", 2e-4), ("f64", 2e-7)):   # rounding-limited in fp32; fp64 build: RK4 truncation error only (measured 3e-8 over these 300 steps)
         cfg = amd._lib.default_config("hexa_arm", n)
         cfg.vehicle.g = 0.0
         for r in range(8):
@@ -246,14 +248,15 @@ def test_arm_long_run_stays_finite():
     assert s["episodes"] > 10000 and s["episodes"] == s["terminated"] + s["truncated"]
 
 
+@pytest.mark.parametrize("kernel", ["lane", "team"])
 @pytest.mark.parametrize("ee_task", ["tool", "base"])
-def test_forward_kinematics_and_tool_point_task_vs_oracle(ee_task):
+def test_forward_kinematics_and_tool_point_task_vs_oracle(ee_task, kernel):
     """amenv_ee_position / obs[26:29] (forward kinematics) and the task point of the reward / reach test against the fp64 oracle, on
     random attitudes and joint angles, for both task modes; a third of the envs sit with the TASK point inside the waypoint ball."""
     import rl_aerial_manipulator_amd as amd
     n = 4096
     rng = np.random.RandomState(11)
-    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, ee_task=ee_task, kernel="lane")
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, ee_task=ee_task, kernel=kernel)
     orc = orc_arm(n, seed=4)
     orc.cfg.task.ee_task = O.EE_TASK_TOOL if ee_task == "tool" else O.EE_TASK_BASE
     env.reset()
@@ -283,3 +286,47 @@ def test_forward_kinematics_and_tool_point_task_vs_oracle(ee_task):
     assert rel_err(g["obs"][ok], o["obs"][ok]).max() < REL32
     assert (np.abs(g["reward"] - o["reward"]) / np.maximum(1, np.abs(o["reward"])))[ok].max() < 5e-5
     env.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 65, 300, 4096])
+def test_team_kernel_tracks_the_lane_kernel(n):
+    """The lane-team kernel (AMENV_KERNEL_TEAM: 16 lanes per env, DPP exchanges) against the one-lane-per-env kernel on the same inputs:
+    same resets (bit-exact: same Philox words, same fp32 arithmetic), same flags, states within fp32 rounding after every step
+    (sums are associated differently, so not bit for bit), Monitor totals equal; ragged batches write nothing past row n."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    T = 150
+    g = torch.Generator(device="cuda").manual_seed(7)
+    acts = torch.randn(T, n, 7, device="cuda", generator=g) * 0.2
+    acts[..., 0] += 1.0
+    acts[:, ::3, 0] = 0.15                      # a third of the envs sink: crashes and auto-resets inside the window
+    acts = acts.clamp(-1, 2)
+    lane = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=6, kernel="lane", max_episode_steps=90)
+    team = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=6, kernel="team", max_episode_steps=90)
+    assert "step_kernel_team" in team.kernel_name
+    o0 = lane.reset().clone(); o1 = team.reset().clone()
+    assert torch.equal(o0, o1)
+    guard = torch.full((n + 8, 29), 7.0, device="cuda")       # the team env writes its observations into rows [0, n) of this buffer only
+    worst = 0.0; flips = 0; dones = 0
+    for t in range(T):
+        f, i = lane.get_state()
+        team.set_state(f, i)                                   # teacher-forced: both kernels step the same state
+        ol, rl, dl, il = (x.clone() for x in lane.step(acts[t]))
+        ot, rt, dt, it = team.step_into(acts[t], guard[:n], team.reward, team.done)
+        same = (il & 127) == (it & 127)
+        flips += int((~same).sum())
+        f1, i1 = lane.get_state(); f2, i2 = team.get_state()
+        nd = same & (dl == 0)
+        if bool(nd.any()):
+            worst = max(worst, float(((f1 - f2).abs() / f1.abs().clamp(min=1.0))[:15][:, nd].max()), float(((f1 - f2).abs() / f1.abs().clamp(min=1.0))[16:][:, nd].max()))
+            assert float((ol[nd] - ot[nd]).abs().max()) < 1e-5 and float(((rl - rt).abs() / rl.abs().clamp(min=1.0))[nd].max()) < 1e-4
+        dn = same & (dl != 0)
+        dones += int(dn.sum())
+        assert torch.equal(f1[:, dn], f2[:, dn]) and torch.equal(i1[:, same], i2[:, same]) and torch.equal(ol[dn], ot[dn])   # reset states / observations: bit-exact
+        if bool(dn.any()):
+            assert torch.equal(lane.ep_len[dn], team.ep_len[dn]) and float((lane.terminal_obs[dn] - team.terminal_obs[dn]).abs().max()) < 1e-5
+    assert worst < 2e-6 and flips <= max(2, n // 500) and dones >= n // 4, (worst, flips, dones)
+    assert bool((guard[n:] == 7.0).all())
+    sl, st = lane.stats(), team.stats()
+    assert abs(sl["episodes"] - st["episodes"]) <= flips and sl["steps"] == st["steps"]
+    lane.close(); team.close()
