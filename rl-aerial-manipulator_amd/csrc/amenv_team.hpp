@@ -42,7 +42,10 @@ template <int N> __device__ __forceinline__ float row_ror(float v) {   // rotate
 template <int J> __device__ __forceinline__ float bc(float v) { return qp<J, J, J, J>(v); }          // component J to the whole quad
 __device__ __forceinline__ float rot1(float v) { return qp<1, 2, 0, 3>(v); }                          // v[(c+1)%3]
 __device__ __forceinline__ float rot2(float v) { return qp<2, 0, 1, 3>(v); }                          // v[(c+2)%3]
-__device__ __forceinline__ float sum_bodies(float v) { v = v + row_ror<4>(v); return v + row_ror<8>(v); }   // over the 4 quads of the row
+// Sum over the 4 quads of the row, BIT-IDENTICAL in all of them: opposite quads first (x0 + x2 and x2 + x0 are the same number), then
+// the two pair sums (a + b = b + a).  With neighbours first each quad would associate the four terms differently, the replicated base
+// state would drift apart between the quads by rounding, and a threshold of the task step could then be taken differently inside one row.
+__device__ __forceinline__ float sum_bodies(float v) { v = v + row_ror<8>(v); return v + row_ror<4>(v); }
 __device__ __forceinline__ float sum4(float p) { const float t = p + qp<1, 0, 3, 2>(p); return t + qp<2, 3, 0, 1>(t); }   // all 4 lanes valid in, all out
 __device__ __forceinline__ float dot3(float a, float b) { const float p = a * b; return (p + rot1(p)) + rot2(p); }        // lanes 0..2
 __device__ __forceinline__ float dot_all(float a, float b) { const float p = a * b; return (bc<0>(p) + bc<1>(p)) + bc<2>(p); }   // all 4 lanes
@@ -54,8 +57,8 @@ struct TM { float c0, c1, c2; };  // 3x3 matrix: lane i holds row i, one registe
 __device__ __forceinline__ float matvec(const TM& M, float v) { return fma_(M.c0, bc<0>(v), fma_(M.c1, bc<1>(v), M.c2 * bc<2>(v))); }
 
 // ---- parameters -------------------------------------------------------------------------------------------------------------
-// Per-lane constants: a [kTeamConsts][16] fp32 table in HBM (built by amenv_create), entry [k][4*body + component]; each lane loads its
-// column once at kernel entry (the loads overlap the state loads).
+// Per-lane constants: a table in HBM (built by amenv_create), constant k of lane column 4*body + component; each lane loads its column
+// once at kernel entry as 16-byte pieces (the loads overlap the state loads).
 enum TeamConst {
   TC_I00 = 0, TC_I01, TC_I02, TC_I11, TC_I12, TC_I22,   // this body's inertia about its CoM, body-fixed frame (uniform within the quad)
   TC_LCX, TC_LCY, TC_LCZ,                              // this body's CoM in its frame (0 for the base)
@@ -78,9 +81,9 @@ struct TeamParams {          // wave-uniform (SGPRs)
   float kp, kd, amax, mtot, inv_mtot, g, h;
   float tmin[6], tmax[6];
   float ee_home[3];
-  int32_t substeps, max_steps, counter_limit, ee_task;
+  int32_t substeps, max_steps, counter_limit, ee_task, K;   // K = 1 (the task code reads it)
   uint32_t flags;
-  const float* consts;       // [kTeamConsts][16]
+  const float4* consts;      // [(kTeamConsts + 3) / 4][16] float4: constants 4k..4k+3 of lane column l at [k][l]
 };
 
 struct TeamState { float P, V, Q, W, TH, THD; };   // one register each: position, velocity (component per lane), quaternion (4 lanes), body rates, joints
@@ -97,32 +100,38 @@ __device__ __forceinline__ void rotate_cols(TM& R, float s, float co) {
   b = fma_(co, rb, -(s * ra));
 }
 
-// 19 derivatives of the arm vehicle in team form.  Same model as arm_rhs_body (amenv_arm.hpp).  F: total thrust (all lanes), Mv: rotor
-// moments, cmd: joint commands (component per lane).  c[]: this lane's constants.
-__device__ __forceinline__ TeamState team_rhs(const TeamParams& P, const float* c, const TeamState& y, float F, float Mv, float cmd) {
-  TeamState d;
+// cross product a x b when only `a` has its rotations cached: the other operand's rotations ride as DPP modifiers of the two
+// multiplies (v_mul_f32_dpp; an FMA cannot carry one), so no v_mov_b32_dpp is spent on `b`
+__device__ __forceinline__ float cross_c(const X3& a, float b) { return a.r1 * rot2(b) - a.r2 * rot1(b); }
+
+// One RK4 stage is evaluated in two parts.  The joint servos do not feel the base, so the joint states of all four stages are known
+// up front, and with them everything that depends on the joint configuration only (team_kin): chain kinematics, each body's CoM motion
+// relative to the body frame, inertias in body axes, the composite inertia about the system CoM and its adjugate.  The four team_kin
+// evaluations are independent of each other -- the compiler interleaves them, which is what a lone wavefront needs to issue at its
+// full rate (one VALU instruction per 4 clocks when independent, ~5.5 when each waits for its predecessor) -- and only team_dyn (the
+// terms with the base's attitude and rates, ~1/3 of the work) forms the serial chain stage 1 -> 2 -> 3 -> 4.
+struct TeamKin {
+  X3 r, u, w;        // this body: CoM position, velocity (relative to the body frame), angular velocity relative to the base
+  float a_, al;      // CoM acceleration, angular acceleration (relative)
+  TM J;              // inertia about the CoM, body axes
+  X3 S;              // sum over bodies of m r
+  TM C;              // adjugate of the composite inertia I_c about the system CoM (columns)
+  float idet;        // 1 / det I_c
+};
+
+__device__ __forceinline__ float joint_accel(const TeamParams& P, float cmd, float th, float thd) {   // servo, joint k in lane k
+  return clamp_(fma_(P.kp, cmd - th, -(P.kd * thd)), -P.amax, P.amax);
+}
+
+__device__ __forceinline__ TeamKin team_kin(const TeamParams& P, const float* c, float TH, float THD, float thdd) {
+  TeamKin k;
   const float e0 = c[TC_E0], e1 = c[TC_E1], e2 = c[TC_E2];
-  // attitude: |q|^2, vector part of q in component layout (with rotations), scalar part
-  const float n2 = sum4(y.Q * y.Q);
-  const float two_in2 = 2.0f * rcp_(n2);
-  const X3 qv{qp<1, 2, 3, 3>(y.Q), qp<2, 3, 1, 3>(y.Q), qp<3, 1, 2, 3>(y.Q)};
-  const float qw = bc<0>(y.Q);
-  const X3 om = x3(y.W);
-  // gravity in body components: Rq (0,0,-g) = v + (2/|q|^2) qv x (qv x v + qw v)
-  float gb;
-  {
-    const X3 gv{c[TC_GV], c[TC_GV1], c[TC_GV2]};
-    const float t = fma_(qw, gv.v, cross(qv, gv));
-    gb = fma_(two_in2, cross(qv, x3(t)), gv.v);
-  }
-  // joint servos (joint k in lane k)
-  const float thdd = clamp_(fma_(P.kp, cmd - y.TH, -(P.kd * y.THD)), -P.amax, P.amax);
   // ---- chain across the joints this body sits behind (masks mk: 1 behind joint k, else 0 -> angle, rate, acceleration, offset vanish)
   TM R;
   float p, pd, pdd, w, al;
   {   // joint 1 about z at the start of the chain: R = 1, p = pd = pdd = w = al = 0
     const float mk = c[TC_MK0];
-    const float th = bc<0>(y.TH) * mk, td = bc<0>(y.THD) * mk, tdd = bc<0>(thdd) * mk;
+    const float th = bc<0>(TH) * mk, td = bc<0>(THD) * mk, tdd = bc<0>(thdd) * mk;
     float s, co;
     sincos_t(th, s, co);
     p = mk * c[TC_O0]; pd = 0.0f; pdd = 0.0f;
@@ -133,74 +142,90 @@ __device__ __forceinline__ TeamState team_rhs(const TeamParams& P, const float* 
     float s, co;
     sincos_t(th, s, co);
     const float Ro = fma_(R.c0, o[0], fma_(R.c1, o[1], R.c2 * o[2]));
-    const X3 xRo = x3(Ro), xw = x3(w), xal = x3(al);
+    const X3 xRo = x3(Ro), xw = x3(w);
     const float wRo = cross(xw, xRo);
     pd = fma_(mk, wRo, pd);
-    pdd = fma_(mk, cross(xal, xRo) + cross(xw, x3(wRo)), pdd);
+    pdd = fma_(mk, cross_c(xw, wRo) - cross_c(xRo, al), pdd);      // al x Ro + w x (w x Ro)
     p = fma_(mk, Ro, p);
     const float z = R.c0;
-    const float wz = cross(xw, x3(z));
+    const float wz = cross_c(xw, z);
     al = fma_(td, wz, fma_(tdd, z, al));
     w = fma_(td, z, w);
     rotate_cols<0>(R, s, co);
   };
-  advance_x(c[TC_MK1], bc<1>(y.TH) * c[TC_MK1], bc<1>(y.THD) * c[TC_MK1], bc<1>(thdd) * c[TC_MK1], P.o1);
-  advance_x(c[TC_MK2], bc<2>(y.TH) * c[TC_MK2], bc<2>(y.THD) * c[TC_MK2], bc<2>(thdd) * c[TC_MK2], P.o2);
-  // ---- this body: CoM motion relative to the body frame, inertia in body axes, its Newton-Euler terms
+  advance_x(c[TC_MK1], bc<1>(TH) * c[TC_MK1], bc<1>(THD) * c[TC_MK1], bc<1>(thdd) * c[TC_MK1], P.o1);
+  advance_x(c[TC_MK2], bc<2>(TH) * c[TC_MK2], bc<2>(THD) * c[TC_MK2], bc<2>(thdd) * c[TC_MK2], P.o2);
+  // ---- this body: CoM motion relative to the body frame, inertia in body axes
   const float m = c[TC_MASS];
   const float Rc = fma_(R.c0, c[TC_LCX], fma_(R.c1, c[TC_LCY], R.c2 * c[TC_LCZ]));
-  const X3 xw = x3(w), xal = x3(al), xRc = x3(Rc);
-  const float wRc = cross(xw, xRc);
-  const float r = p + Rc, u = pd + wRc;
-  const float a_ = pdd + cross(xal, xRc) + cross(xw, x3(wRc));
-  TM J;   // J = R I R^T
-  {
+  k.w = x3(w); k.al = al;
+  const X3 xRc = x3(Rc);
+  const float wRc = cross(k.w, xRc);
+  const float r = p + Rc;
+  k.r = x3(r);
+  k.u = x3(pd + wRc);
+  k.a_ = pdd + cross_c(k.w, wRc) - cross_c(xRc, al);
+  {   // J = R I R^T
     const float RI0 = fma_(R.c0, c[TC_I00], fma_(R.c1, c[TC_I01], R.c2 * c[TC_I02]));
     const float RI1 = fma_(R.c0, c[TC_I01], fma_(R.c1, c[TC_I11], R.c2 * c[TC_I12]));
     const float RI2 = fma_(R.c0, c[TC_I02], fma_(R.c1, c[TC_I12], R.c2 * c[TC_I22]));
-    J.c0 = fma_(RI0, bc<0>(R.c0), fma_(RI1, bc<0>(R.c1), RI2 * bc<0>(R.c2)));
-    J.c1 = fma_(RI0, bc<1>(R.c0), fma_(RI1, bc<1>(R.c1), RI2 * bc<1>(R.c2)));
-    J.c2 = fma_(RI0, bc<2>(R.c0), fma_(RI1, bc<2>(R.c1), RI2 * bc<2>(R.c2)));
+    k.J.c0 = fma_(RI0, bc<0>(R.c0), fma_(RI1, bc<0>(R.c1), RI2 * bc<0>(R.c2)));
+    k.J.c1 = fma_(RI0, bc<1>(R.c0), fma_(RI1, bc<1>(R.c1), RI2 * bc<1>(R.c2)));
+    k.J.c2 = fma_(RI0, bc<2>(R.c0), fma_(RI1, bc<2>(R.c1), RI2 * bc<2>(R.c2)));
   }
-  const X3 xr = x3(r);
-  const float b_ = cross(om, x3(cross(om, xr))) + 2.0f * cross(om, x3(u)) + a_;     // w x (w x r) + 2 w x u + a
-  const float aa = al + cross(om, xw), Om = y.W + w;
-  float S = m * r, fb = m * b_;
-  float nb = m * cross(xr, x3(b_)) + matvec(J, aa) + cross(x3(Om), x3(matvec(J, Om)));
-  const float r2 = dot3(r, r);
-  const float mr2 = m * r2;
-  float IO0 = fma_(-m, r * bc<0>(r), fma_(mr2, e0, J.c0));       // I_O += J + m (|r|^2 1 - r r^T), column by column
-  float IO1 = fma_(-m, r * bc<1>(r), fma_(mr2, e1, J.c1));
-  float IO2 = fma_(-m, r * bc<2>(r), fma_(mr2, e2, J.c2));
-  // ---- sums over the four bodies of the row
-  S = sum_bodies(S); fb = sum_bodies(fb); nb = sum_bodies(nb);
-  IO0 = sum_bodies(IO0); IO1 = sum_bodies(IO1); IO2 = sum_bodies(IO2);
-  // ---- external wrench about O, composite inertia about the system CoM, 3x3 solve by the adjugate (columns = cross products)
-  const float f = fma_(F, e2, fma_(P.mtot, gb, -fb));
-  const X3 xS = x3(S);
-  const float n = Mv + cross(xS, x3(gb)) - nb;
+  // ---- sums over the four bodies of the row: S = sum m r, I_O = sum J + m (|r|^2 1 - r r^T) (column by column)
+  const float mr2 = m * dot3(r, r);
+  const float S = sum_bodies(m * r);
+  const float IO0 = sum_bodies(fma_(-m, r * bc<0>(r), fma_(mr2, e0, k.J.c0)));
+  const float IO1 = sum_bodies(fma_(-m, r * bc<1>(r), fma_(mr2, e1, k.J.c1)));
+  const float IO2 = sum_bodies(fma_(-m, r * bc<2>(r), fma_(mr2, e2, k.J.c2)));
+  k.S = x3(S);
+  // composite inertia about the system CoM, I_c = I_O - (|S|^2 1 - S S^T) / mtot, and its adjugate (columns = cross products of columns)
   const float im = P.inv_mtot;
-  const float imS2 = im * dot3(S, S);
-  const float imS = im * S;
-  const float a0 = fma_(imS, bc<0>(S), fma_(-imS2, e0, IO0));    // I_c = I_O - (|S|^2 1 - S S^T) / mtot
-  const float a1 = fma_(imS, bc<1>(S), fma_(-imS2, e1, IO1));
-  const float a2 = fma_(imS, bc<2>(S), fma_(-imS2, e2, IO2));
-  const float rhs = n - im * cross(xS, x3(f));
-  const X3 x0 = x3(a0), x1 = x3(a1), x2 = x3(a2);
-  const TM C{cross(x1, x2), cross(x2, x0), cross(x0, x1)};
-  const float idet = rcp_(dot3(a0, C.c0));
-  const float wd = idet * matvec(C, rhs);
-  const float Aacc = im * (f + cross(xS, x3(wd)));
+  const float imS2 = im * dot3(S, S), imS = im * S;
+  const X3 x0 = x3(fma_(imS, bc<0>(S), fma_(-imS2, e0, IO0)));
+  const X3 x1 = x3(fma_(imS, bc<1>(S), fma_(-imS2, e1, IO1)));
+  const X3 x2 = x3(fma_(imS, bc<2>(S), fma_(-imS2, e2, IO2)));
+  k.C = TM{cross(x1, x2), cross(x2, x0), cross(x0, x1)};
+  k.idet = rcp_(dot3(x0.v, k.C.c0));
+  return k;
+}
+
+struct TeamDeriv { float V, Q, W; };   // derivatives of velocity, quaternion, body rates (position' = velocity, joints: known up front)
+
+__device__ __forceinline__ TeamDeriv team_dyn(const TeamParams& P, const float* c, const TeamKin& k, float Q, float W, float F, float Mv) {
+  TeamDeriv d;
+  const float e2 = c[TC_E2], m = c[TC_MASS], im = P.inv_mtot;
+  // attitude: |q|^2, vector part of q in component layout (with rotations), scalar part
+  const float n2 = sum4(Q * Q);
+  const float two_in2 = 2.0f * rcp_(n2);
+  const X3 qv{qp<1, 2, 3, 3>(Q), qp<2, 3, 1, 3>(Q), qp<3, 1, 2, 3>(Q)};
+  const float qw = bc<0>(Q);
+  const X3 om = x3(W);
+  // gravity in body components: Rq (0,0,-g) = v + (2/|q|^2) qv x (qv x v + qw v)
+  const X3 gv{c[TC_GV], c[TC_GV1], c[TC_GV2]};
+  const float gb = fma_(two_in2, cross_c(qv, fma_(qw, gv.v, cross(qv, gv))), gv.v);
+  // this body's Newton-Euler terms that involve the base's angular velocity
+  const float b_ = fma_(2.0f, cross(om, k.u), cross_c(om, cross(om, k.r))) + k.a_;      // w x (w x r) + 2 w x u + a
+  const float aa = k.al + cross(om, k.w), Om = W + k.w.v;
+  const float JOm = matvec(k.J, Om);
+  float nb = fma_(m, cross_c(k.r, b_), matvec(k.J, aa)) + cross_c(x3(Om), JOm);
+  float fb = m * b_;
+  fb = sum_bodies(fb); nb = sum_bodies(nb);
+  // external wrench about O, 3x3 solve with the prepared adjugate
+  const float f = fma_(F, e2, fma_(P.mtot, gb, -fb));
+  const float n = Mv + cross_c(k.S, gb) - nb;
+  const float rhs = fma_(-im, cross_c(k.S, f), n);
+  const float wd = k.idet * matvec(k.C, rhs);
+  const float Aacc = im * (f + cross_c(k.S, wd));
   // world acceleration of O: Rq^T A = A + (2/|q|^2) qv x (qv x A - qw A)
-  const float t = fma_(-qw, Aacc, cross(qv, x3(Aacc)));
-  const float vd = fma_(two_in2, cross(qv, x3(t)), Aacc);
+  const float vd = fma_(two_in2, cross_c(qv, fma_(-qw, Aacc, cross_c(qv, Aacc))), Aacc);
   // quaternion kinematics (4 lanes): -1/2 Omega(w) q + 2 (1 - |q|^2) q
-  const float kq = fma_(-2.0f, n2, 2.0f);
-  float dq = kq * y.Q;
-  dq = fma_(c[TC_SP] * bc<0>(y.W), qp<1, 0, 3, 2>(y.Q), dq);
-  dq = fma_(c[TC_SQ] * bc<1>(y.W), qp<2, 3, 0, 1>(y.Q), dq);
-  dq = fma_(c[TC_SR] * bc<2>(y.W), qp<3, 2, 1, 0>(y.Q), dq);
-  d.P = y.V; d.V = vd; d.Q = dq; d.W = wd; d.TH = y.THD; d.THD = thdd;
+  float dq = fma_(-2.0f, n2, 2.0f) * Q;
+  dq = fma_(c[TC_SP] * bc<0>(W), qp<1, 0, 3, 2>(Q), dq);
+  dq = fma_(c[TC_SQ] * bc<1>(W), qp<2, 3, 0, 1>(Q), dq);
+  dq = fma_(c[TC_SR] * bc<2>(W), qp<3, 2, 1, 0>(Q), dq);
+  d.V = vd; d.Q = dq; d.W = wd;
   return d;
 }
 
@@ -221,37 +246,77 @@ __device__ __forceinline__ float team_tool_offset(const TeamParams& P, const flo
   // world = Rq^T body (|q| = 1)
   const X3 qv{qp<1, 2, 3, 3>(y.Q), qp<2, 3, 1, 3>(y.Q), qp<3, 1, 2, 3>(y.Q)};
   const float qw = bc<0>(y.Q);
-  const float t = fma_(-qw, p, cross(qv, x3(p)));
-  return fma_(2.0f, cross(qv, x3(t)), p);
+  return fma_(2.0f, cross_c(qv, fma_(-qw, p, cross_c(qv, p))), p);
 }
 
-// One control step of 4 envs per wavefront.  grid = ceil(n_tiles * 64 / 4) workgroups of 64 threads.
-template <int NROT>
-__global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float* __restrict__ actions,
-                                                       float* __restrict__ obs, float* __restrict__ reward_out, uint8_t* __restrict__ done,
-                                                       uint32_t* __restrict__ info, const StepTail tl, const HotParams<float, NROT> HP, const ColdParams C,
-                                                       const TeamParams P) {
-  static_assert(NROT == 6, "team kernel: 6-rotor airframe");
-  constexpr int OD = 29, AD = 7;
-  const int lane = int(threadIdx.x);
-  const int cc = lane & 3, bb = (lane >> 2) & 3;
-  const int i = int(blockIdx.x) * 4 + (lane >> 4);          // env of this row
-  const bool active = i < n_envs;
-  const int ia = active ? i : n_envs - 1;                   // rows past the end redo the last env's arithmetic (their stores are masked)
-  char* tile = static_cast<char*>(blob) + size_t(i >> 6) * tile_bytes;
-  const uint32_t eoff = uint32_t(i & 63) * 16u + uint32_t(cc) * 4u;
-  auto gload = [&](int g) { return *reinterpret_cast<const float*>(tile + kIntBytes + uint32_t(g) * 1024u + eoff); };
-  // per-lane constants
-  float c[kTeamConsts];
+// ---- one env row's registers, and the per-lane role of a lane in its team -------------------------------------------------------------
+struct TeamEnv {
+  TeamState y;                                   // dynamic state (component per lane, replicated in the four quads)
+  float WP;                                      // waypoint (component per lane)
+  float final_yaw, last_distance, ep_return;     // per-env scalars, replicated in all 16 lanes
+  int32_t step, counter, flags, episode;
+};
+
+struct TeamLane {
+  int lane, cc, bb;
+  bool q0, q1, q2, lead;
+  uint32_t offA, offB, offC;                     // observation columns this lane writes in the three row segments
+  bool okA, okB, okC;
+  float c[((kTeamConsts + 3) / 4) * 4];          // this lane's constants
+  __device__ __forceinline__ void init(const TeamParams& P) {
+    lane = int(threadIdx.x) & 63; cc = lane & 3; bb = (lane >> 2) & 3;
+    q0 = bb == 0; q1 = bb == 1; q2 = bb == 2; lead = (lane & 15) == 0;
+    // A = [p/10 | v/5 | q | w/5] by quad, B = [(wp - task point)/2 | 0 | yaw/pi | th/pi], C = [thd/5 | tool offset*2]
+    offA = q0 ? cc : (q1 ? 3 + cc : (q2 ? 6 + cc : 10 + cc));
+    offB = q0 ? 13 + cc : (q1 ? 16 + cc : (q2 ? 19 : 20 + cc));
+    offC = q0 ? 23 + cc : 26 + cc;
+    okA = cc < 3 || q2; okB = q2 ? cc == 0 : cc < 3; okC = cc < 3 && bb < 2;
+    constexpr int NC4 = (kTeamConsts + 3) / 4;
 #pragma unroll
-  for (int k = 0; k < kTeamConsts; k++) c[k] = P.consts[k * 16 + (lane & 15)];
-  // state (every quad of the row holds a copy), per-env scalars ride in lane 3 of the p / v / w groups
-  TeamState y{gload(0), gload(1), gload(2), gload(3), gload(5), gload(6)};
-  const float WPv = gload(4);
+    for (int k = 0; k < NC4; k++) {
+      const float4 v = P.consts[k * 16 + (lane & 15)];
+      c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+    }
+  }
+};
+
+// state of env i from its tile: lane c of every quad reads component c of each group; the per-env scalars ride in slot 3 of the
+// p / v / w groups
+__device__ __forceinline__ void team_load(const char* tile, int i, const TeamLane& L, TeamEnv& E) {
+  const uint32_t eoff = uint32_t(i & 63) * 16u + uint32_t(L.cc) * 4u;
+  auto gload = [&](int g) { return *reinterpret_cast<const float*>(tile + kIntBytes + uint32_t(g) * 1024u + eoff); };
+  E.y = TeamState{gload(0), gload(1), gload(2), gload(3), gload(5), gload(6)};
+  E.WP = gload(4);
   const int4 iv = *(reinterpret_cast<const int4*>(tile) + (i & 63));
-  const float act = actions[size_t(ia) * AD + cc];                                     // a0..a3: one per lane
-  const float actj = actions[size_t(ia) * AD + 4 + (cc < 3 ? cc : 2)];                  // joint commands a4..a6
-  const float final_yaw = bc<3>(y.P), last_distance = bc<3>(y.V), ep_return0 = bc<3>(y.W);
+  E.final_yaw = bc<3>(E.y.P); E.last_distance = bc<3>(E.y.V); E.ep_return = bc<3>(E.y.W);
+  E.step = iv.x; E.counter = iv.y; E.flags = iv.z; E.episode = iv.w;
+}
+
+// quad b writes group b (p|yaw, v|last_distance, q, w|return), then joints (quads 0, 1), the int plane (quad 2) and, after a reset, the waypoint
+__device__ __forceinline__ void team_store(char* tile, int i, const TeamLane& L, const TeamEnv& E, bool store_waypoint) {
+  const uint32_t eoff = uint32_t(i & 63) * 16u + uint32_t(L.cc) * 4u;
+  const bool l3 = L.cc == 3;
+  const float g0 = l3 ? E.final_yaw : E.y.P, g1 = l3 ? E.last_distance : E.y.V, g3 = l3 ? E.ep_return : E.y.W;
+  const float sv = L.q0 ? g0 : (L.q1 ? g1 : (L.q2 ? E.y.Q : g3));
+  *reinterpret_cast<float*>(tile + kIntBytes + uint32_t(L.bb) * 1024u + eoff) = sv;
+  if (L.bb < 2) *reinterpret_cast<float*>(tile + kIntBytes + uint32_t(5 + L.bb) * 1024u + eoff) = L.q0 ? E.y.TH : E.y.THD;
+  if (L.q2) {
+    const int ival = L.cc == 0 ? E.step : (L.cc == 1 ? E.counter : (L.cc == 2 ? E.flags : E.episode));
+    *(reinterpret_cast<int*>(tile) + (i & 63) * 4 + L.cc) = ival;
+  }
+  if (L.bb == 3 && store_waypoint) *reinterpret_cast<float*>(tile + kIntBytes + 4u * 1024u + eoff) = E.WP;
+}
+
+struct TeamOut { float reward; uint32_t bits; float vA, vB, vC; bool ended; int ep_len; float ep_ret; };
+
+// One control step of one env row, state in registers: mixer -> RK4 -> forward kinematics -> task step -> (episode end: Monitor outputs,
+// reset) -> observation values.  act: wrench action a0..a3 (one per lane), actj: joint commands (joint per lane).
+template <int NROT>
+__device__ __forceinline__ TeamOut team_advance(const TeamParams& P, const ColdParams& C, const TeamLane& L, TeamEnv& E, float act, float actj, int i, bool active,
+                                                float* terminal_obs, float* ep_return_out, int32_t* ep_len_out) {
+  constexpr int OD = 29;
+  const float* c = L.c;
+  TeamState& y = E.y;
   // mixer -> per-rotor clamp -> re-mix (quadcopter.py:109-112); wrench entry per lane
   const float uu = (act * c[TC_ACT1]) * c[TC_ACT2];
   float wr = 0.0f;
@@ -263,27 +328,31 @@ __global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, 
   }
   const float F = bc<0>(wr), Mv = qp<1, 2, 3, 3>(wr);
   const float cmd = __builtin_fmaf(actj, c[TC_JHALF], c[TC_JMID]);
-  // RK4 (running weighted sum)
+  // RK4 (running weighted sum).  Joint stage states first (the servos do not feel the base), then the four joint-configuration parts,
+  // then the serial chain of base-dependent parts.
   const float h = P.h, hh = 0.5f * h, h6 = h * (1.0f / 6.0f);
   int it = 0;
   do {
-    TeamState k = team_rhs(P, c, y, F, Mv, cmd), acc = k, s;
-#define AMENV_TS(OP) OP(P) OP(V) OP(Q) OP(W) OP(TH) OP(THD)
-#define ST1(f) s.f = fma_(hh, k.f, y.f);
-    AMENV_TS(ST1)
-    k = team_rhs(P, c, s, F, Mv, cmd);
-#define ST2(f) acc.f = fma_(2.0f, k.f, acc.f); s.f = fma_(hh, k.f, y.f);
-    AMENV_TS(ST2)
-    k = team_rhs(P, c, s, F, Mv, cmd);
-#define ST3(f) acc.f = fma_(2.0f, k.f, acc.f); s.f = fma_(h, k.f, y.f);
-    AMENV_TS(ST3)
-    k = team_rhs(P, c, s, F, Mv, cmd);
-#define ST4(f) y.f = fma_(h6, acc.f + k.f, y.f);
-    AMENV_TS(ST4)
-#undef ST1
-#undef ST2
-#undef ST3
-#undef ST4
+    const float a1 = joint_accel(P, cmd, y.TH, y.THD);
+    const float TH2 = fma_(hh, y.THD, y.TH), THD2 = fma_(hh, a1, y.THD), a2 = joint_accel(P, cmd, TH2, THD2);
+    const float TH3 = fma_(hh, THD2, y.TH), THD3 = fma_(hh, a2, y.THD), a3 = joint_accel(P, cmd, TH3, THD3);
+    const float TH4 = fma_(h, THD3, y.TH), THD4 = fma_(h, a3, y.THD), a4 = joint_accel(P, cmd, TH4, THD4);
+    const TeamKin k1 = team_kin(P, c, y.TH, y.THD, a1), k2 = team_kin(P, c, TH2, THD2, a2), k3 = team_kin(P, c, TH3, THD3, a3),
+                  k4 = team_kin(P, c, TH4, THD4, a4);
+    TeamDeriv d = team_dyn(P, c, k1, y.Q, y.W, F, Mv);
+    float aP = y.V, aV = d.V, aQ = d.Q, aW = d.W;                       // acc = k1
+    float sV = fma_(hh, d.V, y.V), sQ = fma_(hh, d.Q, y.Q), sW = fma_(hh, d.W, y.W);
+    d = team_dyn(P, c, k2, sQ, sW, F, Mv);
+    aP = fma_(2.0f, sV, aP); aV = fma_(2.0f, d.V, aV); aQ = fma_(2.0f, d.Q, aQ); aW = fma_(2.0f, d.W, aW);
+    sV = fma_(hh, d.V, y.V); sQ = fma_(hh, d.Q, y.Q); sW = fma_(hh, d.W, y.W);
+    d = team_dyn(P, c, k3, sQ, sW, F, Mv);
+    aP = fma_(2.0f, sV, aP); aV = fma_(2.0f, d.V, aV); aQ = fma_(2.0f, d.Q, aQ); aW = fma_(2.0f, d.W, aW);
+    sV = fma_(h, d.V, y.V); sQ = fma_(h, d.Q, y.Q); sW = fma_(h, d.W, y.W);
+    d = team_dyn(P, c, k4, sQ, sW, F, Mv);
+    y.P = fma_(h6, aP + sV, y.P); y.V = fma_(h6, aV + d.V, y.V); y.Q = fma_(h6, aQ + d.Q, y.Q); y.W = fma_(h6, aW + d.W, y.W);
+    const float nTH = fma_(h6, fma_(2.0f, THD3, fma_(2.0f, THD2, y.THD)) + THD4, y.TH);
+    y.THD = fma_(h6, fma_(2.0f, a3, fma_(2.0f, a2, a1)) + a4, y.THD);
+    y.TH = nTH;
   } while (++it < P.substeps);
   y.Q = y.Q * rsqrt_(sum4(y.Q * y.Q));
   const float EO = team_tool_offset(P, c, y);
@@ -293,54 +362,44 @@ __global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, 
   e.vx = bc<0>(y.V); e.vy = bc<1>(y.V); e.vz = bc<2>(y.V);
   e.qw = bc<0>(y.Q); e.qx = bc<1>(y.Q); e.qy = bc<2>(y.Q); e.qz = bc<3>(y.Q);
   e.wx = bc<0>(y.W); e.wy = bc<1>(y.W); e.wz = bc<2>(y.W);
-  e.wp[0][0] = bc<0>(WPv); e.wp[0][1] = bc<1>(WPv); e.wp[0][2] = bc<2>(WPv);
+  e.wp[0][0] = bc<0>(E.WP); e.wp[0][1] = bc<1>(E.WP); e.wp[0][2] = bc<2>(E.WP);
   e.eox = bc<0>(EO); e.eoy = bc<1>(EO); e.eoz = bc<2>(EO);
 #pragma unroll
   for (int k = 0; k < 3; k++) { e.th[k] = 0.0f; e.thd[k] = 0.0f; }    // (joints stay in team registers; the task code does not read them)
-  e.final_yaw = final_yaw; e.last_distance = last_distance; e.ep_return = ep_return0;
-  e.step = iv.x; e.counter = iv.y; e.flags = iv.z; e.episode = iv.w;
-  float reward;
-  uint32_t bits = task_step<float, 1, true>(HP, e, reward);
-  e.ep_return += reward;
-  // observation segments of this lane: A = [p/10 | v/5 | q | w/5] by quad, B = [(wp - task point)/2 | 0 | yaw/pi | th/pi], C = [thd/5 | tool offset*2]
-  const bool q0 = bb == 0, q1 = bb == 1, q2 = bb == 2;
-  auto obs_vals = [&](const TeamState& z, float wpv, float eo, float fyaw, float& vA, float& vB, float& vC) {
-    vA = (q0 ? z.P : (q1 ? z.V : (q2 ? z.Q : z.W))) * c[TC_OBS_A];
-    const float tp = HP.ee_task != 0 ? z.P + eo : z.P;
-    vB = (q0 ? wpv - tp : (q1 ? 0.0f : (q2 ? fyaw : z.TH))) * c[TC_OBS_B];
-    vC = (q0 ? z.THD : eo) * c[TC_OBS_C];
+  e.final_yaw = E.final_yaw; e.last_distance = E.last_distance; e.ep_return = E.ep_return;
+  e.step = E.step; e.counter = E.counter; e.flags = E.flags; e.episode = E.episode;
+  TeamOut o;
+  o.bits = task_step<float, 1, true>(P, e, o.reward);
+  e.ep_return += o.reward;
+  auto obs_vals = [&](const TeamState& z, float wpv, float eo, float fyaw) {
+    o.vA = (L.q0 ? z.P : (L.q1 ? z.V : (L.q2 ? z.Q : z.W))) * c[TC_OBS_A];
+    const float tp = P.ee_task != 0 ? z.P + eo : z.P;
+    o.vB = (L.q0 ? wpv - tp : (L.q1 ? 0.0f : (L.q2 ? fyaw : z.TH))) * c[TC_OBS_B];
+    o.vC = (L.q0 ? z.THD : eo) * c[TC_OBS_C];
   };
-  const int offA = q0 ? cc : (q1 ? 3 + cc : (q2 ? 6 + cc : 10 + cc));
-  const int offB = q0 ? 13 + cc : (q1 ? 16 + cc : (q2 ? 19 : 20 + cc));
-  const int offC = q0 ? 23 + cc : 26 + cc;
-  const bool okA = cc < 3 || q2, okB = q2 ? cc == 0 : cc < 3, okC = cc < 3 && bb < 2;
-  float vA, vB, vC;
-  obs_vals(y, WPv, EO, final_yaw, vA, vB, vC);
-  const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
-  const bool resets = ended && (HP.flags & AMENV_FLAG_AUTO_RESET);
-  const bool lead = (lane & 15) == 0;
-  const bool is_done = active && ended;
-  int ep_len = 0; float ep_ret = 0.0f;
-  float WPn = WPv; float fy_n = final_yaw;
-  if (ended) {   // uniform within the row; SB3 DummyVecEnv + Monitor contract
-    ep_len = e.step; ep_ret = e.ep_return;
+  obs_vals(y, E.WP, EO, E.final_yaw);
+  o.ended = (o.bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+  const bool resets = o.ended && (P.flags & AMENV_FLAG_AUTO_RESET);
+  o.ep_len = 0; o.ep_ret = 0.0f;
+  if (o.ended) {   // uniform within the row; SB3 DummyVecEnv + Monitor contract
+    o.ep_len = e.step; o.ep_ret = e.ep_return;
     if (active) {
-      if (tl.terminal_obs) {
-        float* t = tl.terminal_obs + size_t(i) * OD;
-        if (okA) t[offA] = vA;
-        if (okB) t[offB] = vB;
-        if (okC) t[offC] = vC;
+      if (terminal_obs) {
+        const uint32_t row = uint32_t(i) * OD;
+        if (L.okA) terminal_obs[row + L.offA] = o.vA;
+        if (L.okB) terminal_obs[row + L.offB] = o.vB;
+        if (L.okC) terminal_obs[row + L.offC] = o.vC;
       }
-      if (lead) {
-        if (tl.ep_return) tl.ep_return[i] = ep_ret;
-        if (tl.ep_len) tl.ep_len[i] = ep_len;
+      if (L.lead) {
+        if (ep_return_out) ep_return_out[i] = o.ep_ret;
+        if (ep_len_out) ep_len_out[i] = o.ep_len;
       }
     }
     if (resets) {
       // reset RNG: lane c < 3 of every quad computes Philox block c; the 12 words are then broadcast inside the quad
       uint32_t wds[4];
       const int64_t gid = C.gid0 + i;
-      philox4x32_10(C.seed_lo, C.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(e.episode), uint32_t(cc), wds);
+      philox4x32_10(C.seed_lo, C.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(e.episode), uint32_t(L.cc), wds);
       uint32_t r[12];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -351,39 +410,106 @@ __global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, 
       const float e0 = c[TC_E0], e1 = c[TC_E1], e2 = c[TC_E2];
       y.P = fma_(e0, e.px, fma_(e1, e.py, e2 * e.pz));
       y.V = 0.0f; y.W = 0.0f; y.TH = 0.0f; y.THD = 0.0f;
-      y.Q = cc == 0 ? 1.0f : 0.0f;
-      WPn = fma_(e0, e.wp[0][0], fma_(e1, e.wp[0][1], e2 * e.wp[0][2]));
-      fy_n = e.final_yaw;
-      const float EOn = fma_(e0, e.eox, fma_(e1, e.eoy, e2 * e.eoz));
-      obs_vals(y, WPn, EOn, fy_n, vA, vB, vC);
-      bits |= AMENV_INFO_WAS_RESET;
+      y.Q = L.cc == 0 ? 1.0f : 0.0f;
+      E.WP = fma_(e0, e.wp[0][0], fma_(e1, e.wp[0][1], e2 * e.wp[0][2]));
+      E.final_yaw = e.final_yaw;
+      obs_vals(y, E.WP, fma_(e0, e.eox, fma_(e1, e.eoy, e2 * e.eoz)), E.final_yaw);
+      o.bits |= AMENV_INFO_WAS_RESET;
     }
   }
-  accumulate_stats(tl.stats, int(blockIdx.x), bits, is_done && lead, ep_len, ep_ret);
-  // ---- stores.  State: quad b writes group b (p|yaw, v|last_distance, q, w|return), then joints (quads 0, 1) and the int plane (quad 2)
-  {
-    const bool l3 = cc == 3;
-    const float g0 = l3 ? fy_n : y.P, g1 = l3 ? e.last_distance : y.V, g3 = l3 ? e.ep_return : y.W;
-    const float sv = q0 ? g0 : (q1 ? g1 : (q2 ? y.Q : g3));
-    *reinterpret_cast<float*>(tile + kIntBytes + uint32_t(bb) * 1024u + eoff) = sv;
-    if (bb < 2) *reinterpret_cast<float*>(tile + kIntBytes + uint32_t(5 + bb) * 1024u + eoff) = q0 ? y.TH : y.THD;
-    if (q2) {
-      const int ival = cc == 0 ? e.step : (cc == 1 ? e.counter : (cc == 2 ? e.flags : e.episode));
-      *(reinterpret_cast<int*>(tile) + (i & 63) * 4 + cc) = ival;
-    }
-    if (bb == 3 && (bits & AMENV_INFO_WAS_RESET)) *reinterpret_cast<float*>(tile + kIntBytes + 4u * 1024u + eoff) = WPn;   // per-episode: waypoint
-  }
+  E.last_distance = e.last_distance; E.ep_return = e.ep_return;
+  E.step = e.step; E.counter = e.counter; E.flags = e.flags; E.episode = e.episode;
+  return o;
+}
+
+__device__ __forceinline__ void team_store_outputs(const TeamLane& L, const TeamOut& o, uint32_t i, bool active, float* __restrict__ obs, float* __restrict__ reward_out,
+                                                   uint8_t* __restrict__ done, uint32_t* __restrict__ info) {
   if (active) {
-    float* o = obs + size_t(i) * OD;
-    if (okA) o[offA] = vA;
-    if (okB) o[offB] = vB;
-    if (okC) o[offC] = vC;
-    if (lead) {
-      reward_out[i] = reward;
-      done[i] = is_done ? 1 : 0;
-      info[i] = bits;
+    const uint32_t row = i * 29u;
+    if (obs) {
+      if (L.okA) obs[row + L.offA] = o.vA;
+      if (L.okB) obs[row + L.offB] = o.vB;
+      if (L.okC) obs[row + L.offC] = o.vC;
+    }
+    if (L.lead) {
+      if (reward_out) reward_out[i] = o.reward;
+      if (done) done[i] = o.ended ? 1 : 0;
+      if (info) info[i] = o.bits;
     }
   }
+}
+
+// One control step of 4 envs per wavefront.  grid = n_tiles * 16 workgroups of 64 threads.
+template <int NROT>
+__global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float* __restrict__ actions,
+                                                       float* __restrict__ obs, float* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                       uint32_t* __restrict__ info, const StepTail tl, const ColdParams C, const TeamParams P) {
+  static_assert(NROT == 6, "team kernel: 6-rotor airframe");
+  constexpr int AD = 7;
+#ifdef AMENV_STAMPS
+  unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  AMENV_STAMP(0);
+  TeamLane L;
+  L.init(P);
+  const int i = int(blockIdx.x) * 4 + (L.lane >> 4);        // env of this row
+  const bool active = i < n_envs;
+  const int ia = active ? i : n_envs - 1;                   // rows past the end redo the last env's arithmetic (their outputs are masked)
+  char* tile = static_cast<char*>(blob) + size_t(i >> 6) * tile_bytes;
+  TeamEnv E;
+  team_load(tile, i, L, E);
+  const float act = actions[size_t(ia) * AD + L.cc];                                     // a0..a3: one per lane
+  const float actj = actions[size_t(ia) * AD + 4 + (L.cc < 3 ? L.cc : 2)];                // joint commands a4..a6
+  AMENV_STAMP(1);          // loads issued
+  AMENV_STAMP_DRAIN();
+  AMENV_STAMP(2);          // loads landed
+  AMENV_STAMP(3);
+  const TeamOut o = team_advance<NROT>(P, C, L, E, act, actj, i, active, tl.terminal_obs, tl.ep_return, tl.ep_len);
+  AMENV_STAMP(4);          // mixer + RK4 + forward kinematics + task step + episode end / reset
+  accumulate_stats(tl.stats, int(blockIdx.x), o.bits, active && o.ended && L.lead, o.ep_len, o.ep_ret);
+  AMENV_STAMP(5);          // Monitor totals
+  team_store(tile, i, L, E, (o.bits & AMENV_INFO_WAS_RESET) != 0);
+  team_store_outputs(L, o, uint32_t(i), active, obs, reward_out, done, info);
+  AMENV_STAMP(6);          // stores issued
+#ifdef AMENV_STAMPS
+  AMENV_STAMP_DRAIN();
+  AMENV_STAMP(7);          // stores acknowledged
+  if (L.lane == 0 && blockIdx.x < kStampWaves)
+    for (int kk = 0; kk < kStampSlots; kk++) tl.stats[kStampBase + blockIdx.x * kStampSlots + kk] = stamps_[kk];
+#endif
+}
+
+// n_steps control steps per launch with open-loop actions [T][N][7]; per-step outputs [T][N]... (any of them may be null).  State and
+// constants stay in registers across steps: no launch boundary, no prologue, no state traffic between steps.
+template <int NROT>
+__global__ __launch_bounds__(64) void rollout_kernel_team(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float* __restrict__ actions,
+                                                          float* __restrict__ obs, float* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                          uint32_t* __restrict__ info, int n_steps, const StepTail tl, const ColdParams C, const TeamParams P) {
+  constexpr int AD = 7, OD = 29;
+  TeamLane L;
+  L.init(P);
+  const int i = int(blockIdx.x) * 4 + (L.lane >> 4);
+  const bool active = i < n_envs;
+  const int ia = active ? i : n_envs - 1;
+  char* tile = static_cast<char*>(blob) + size_t(i >> 6) * tile_bytes;
+  TeamEnv E;
+  team_load(tile, i, L, E);
+  const size_t n = size_t(n_envs);
+  const uint32_t ja = uint32_t(L.cc < 3 ? L.cc : 2);
+  const float* ap = actions + size_t(ia) * AD;
+  float act = ap[L.cc], actj = ap[4 + ja];
+  bool any_reset = false;
+  for (int t = 0; t < n_steps; t++) {
+    const float a_now = act, aj_now = actj;
+    if (t + 1 < n_steps) { ap += n * AD; act = ap[L.cc]; actj = ap[4 + ja]; }   // next step's action: in flight during this step
+    const TeamOut o = team_advance<NROT>(P, C, L, E, a_now, aj_now, i, active, nullptr, nullptr, nullptr);
+    any_reset |= (o.bits & AMENV_INFO_WAS_RESET) != 0;
+    accumulate_stats(tl.stats, int(blockIdx.x), o.bits, active && o.ended && L.lead, o.ep_len, o.ep_ret);
+    const size_t tn = size_t(t) * n;
+    team_store_outputs(L, o, uint32_t(i), active, obs ? obs + tn * OD : nullptr, reward_out ? reward_out + tn : nullptr, done ? done + tn : nullptr,
+                       info ? info + tn : nullptr);
+  }
+  team_store(tile, i, L, E, any_reset);
 }
 
 }  // namespace amenv_dev

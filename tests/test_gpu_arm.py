@@ -307,7 +307,7 @@ def test_team_kernel_tracks_the_lane_kernel(n):
     o0 = lane.reset().clone(); o1 = team.reset().clone()
     assert torch.equal(o0, o1)
     guard = torch.full((n + 8, 29), 7.0, device="cuda")       # the team env writes its observations into rows [0, n) of this buffer only
-    worst = 0.0; flips = 0; dones = 0
+    worst = 0.0; flips = 0; dones = 0; bonus_flips = 0
     for t in range(T):
         f, i = lane.get_state()
         team.set_state(f, i)                                   # teacher-forced: both kernels step the same state
@@ -319,14 +319,46 @@ def test_team_kernel_tracks_the_lane_kernel(n):
         nd = same & (dl == 0)
         if bool(nd.any()):
             worst = max(worst, float(((f1 - f2).abs() / f1.abs().clamp(min=1.0))[:15][:, nd].max()), float(((f1 - f2).abs() / f1.abs().clamp(min=1.0))[16:][:, nd].max()))
-            assert float((ol[nd] - ot[nd]).abs().max()) < 1e-5 and float(((rl - rt).abs() / rl.abs().clamp(min=1.0))[nd].max()) < 1e-4
+            assert float((ol[nd] - ot[nd]).abs().max()) < 1e-5
+            # rewards agree to rounding except on an env sitting exactly on the `progress > 0` threshold of the +2 bonus
+            # (v2/rl_env_scaledObs.py:214-218): there the two kernels may differ by exactly that bonus
+            dr = (rl - rt).abs()[nd]
+            off = dr / rl.abs().clamp(min=1.0)[nd] >= 1e-4
+            bonus_flips += int(off.sum())
+            assert bool(((dr[off] - 2.0).abs() < 1e-3).all()), dr[off]
         dn = same & (dl != 0)
         dones += int(dn.sum())
         assert torch.equal(f1[:, dn], f2[:, dn]) and torch.equal(i1[:, same], i2[:, same]) and torch.equal(ol[dn], ot[dn])   # reset states / observations: bit-exact
         if bool(dn.any()):
             assert torch.equal(lane.ep_len[dn], team.ep_len[dn]) and float((lane.terminal_obs[dn] - team.terminal_obs[dn]).abs().max()) < 1e-5
-    assert worst < 2e-6 and flips <= max(2, n // 500) and dones >= n // 4, (worst, flips, dones)
+    assert worst < 2e-6 and flips <= max(2, n // 500) and dones >= n // 4 and bonus_flips <= 1e-4 * n * T + 1, (worst, flips, dones, bonus_flips)
     assert bool((guard[n:] == 7.0).all())
     sl, st = lane.stats(), team.stats()
     assert abs(sl["episodes"] - st["episodes"]) <= flips and sl["steps"] == st["steps"]
     lane.close(); team.close()
+
+
+def test_team_rollout_kernel_equals_team_steps():
+    """amenv_rollout on the lane-team kernel (T steps per launch, state and constants in registers between steps) against T single
+    team steps: same code per step, so bit-identical outputs, state and totals; ragged batch."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n, T = 1000, 120
+    g = torch.Generator(device="cuda").manual_seed(11)
+    acts = torch.randn(T, n, 7, device="cuda", generator=g) * 0.2
+    acts[..., 0] += 1.0
+    acts[:, ::3, 0] = 0.15
+    acts = acts.clamp(-1, 2).contiguous()
+    e1 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, kernel="team", max_episode_steps=70)
+    e2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, kernel="team", max_episode_steps=70)
+    e1.reset(); e2.reset()
+    ro = e1.rollout(acts)
+    assert ro["obs"].shape == (T, n, 29)
+    for t in range(T):
+        obs, rew, done, info = e2.step(acts[t])
+        assert torch.equal(ro["obs"][t], obs) and torch.equal(ro["reward"][t], rew) and torch.equal(ro["info_bits"][t], info) and torch.equal(ro["done"][t], done)
+    f1, i1 = e1.get_state(); f2, i2 = e2.get_state()
+    assert torch.equal(f1, f2) and torch.equal(i1, i2) and e1.stats() == e2.stats() and int(ro["done"].sum()) >= n
+    # outputs are optional
+    e1.rollout(acts[:5], want_obs=False, want_flags=False)
+    e1.close(); e2.close()

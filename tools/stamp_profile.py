@@ -16,12 +16,13 @@ ap.add_argument("--vehicle", default="hexa")
 ap.add_argument("--launches", type=int, default=100)
 ap.add_argument("--hover", action="store_true")
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--kernel", default="auto")
 a = ap.parse_args()
 import torch
 
 import rl_aerial_manipulator_amd as amd
 
-env = amd.GpuWaypointEnv(a.envs, vehicle=a.vehicle, seed=a.seed)
+env = amd.GpuWaypointEnv(a.envs, vehicle=a.vehicle, seed=a.seed, kernel=a.kernel)
 env.reset()
 lib = C.CDLL(amd._lib.LIB_PATH)
 lib.amenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
@@ -35,8 +36,11 @@ names = ["entry->loads issued", "loads issued->landed", "compute (mixer+RK4+task
 if "arm2w" in env.kernel_name:   # two-wave arm kernel: stamps of the MAIN wave of each tile
     names = ["entry->loads issued", "loads issued->landed", "RK4 (with helper) + task step", "stats + state/output stores issued",
              "final barrier (helper's obs rows landed)", "reset rows (rare)", "drain stores (vmcnt 0)"]
+if "team" in env.kernel_name:    # lane-team kernel: one wave = 4 envs; stamps of the first 64 waves
+    names = ["entry->loads issued", "loads issued->landed", "-", "mixer + RK4 + forward kinematics + task step + episode end / reset",
+             "Monitor totals", "stores issued", "drain stores (vmcnt 0)"]
 rows, raws = [], []
-nw = min(64, (a.envs + 63) // 64)
+nw = min(64, (a.envs + 63) // 64) if "team" not in env.kernel_name else min(64, (a.envs + 3) // 4)
 for t in range(a.launches):
     env.step(ring[t % 16])
     buf = np.zeros((64, 8), np.uint64)
