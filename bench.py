@@ -396,6 +396,28 @@ def extras(args, amd, torch, env, ring, n, device):
     prot["C_policy_closed_loop"] = {"env_steps_per_s": (S // 8) * n / (ms * 1e-3), "us_per_step": ms * 1e3 / (S // 8),
                                     "fused_policy_kernel": fused, "weights": "random init (reference architecture 128-64-64 tanh)"}
     e3.close()
+    if args.vehicle == "hexa_arm" and args.dtype == "f32":
+        # the same closed loop as ONE launch per 64 steps: amenv_rollout_policy (bf16 actor / critic on the matrix cores, sampling, clip,
+        # team env step; state, constants and weights in registers) -- the opt-in rollout mode of amd.PPO(fused_rollout=True)
+        e4 = amd.GpuWaypointEnv(n, device=device.index, vehicle=args.vehicle, seed=0, kernel=args.kernel)
+        e4.reset()
+        Tf = GRAPH_CHUNK
+        f = dict(dtype=torch.float32, device=device)
+        bo, ba = torch.zeros(Tf + 1, n, e4.obs_dim, **f), torch.zeros(Tf, n, e4.act_dim, **f)
+        bl, bv, br = torch.zeros(Tf, n, **f), torch.zeros(Tf, n, **f), torch.zeros(Tf, n, **f)
+        bd = torch.zeros(Tf, n, dtype=torch.uint8, device=device)
+        draw = [0]
+
+        def fused():
+            for _ in range(S // Tf):
+                e4.rollout_policy(pol.flat_param, Tf, 0, draw[0], bo, ba, bl, bv, br, bd)
+                draw[0] += Tf
+
+        fused()
+        ms = timed(fused, 5)
+        prot["C_policy_closed_loop_one_launch"] = {"env_steps_per_s": S * n / (ms * 1e-3), "us_per_step": ms * 1e3 / S, "steps_per_launch": Tf,
+                                                   "policy_arithmetic": "bf16 MFMA, fp32 accumulate", "what": "amenv_rollout_policy: value + sampled action + log-prob + env step per step, rollout-buffer rows written"}
+        e4.close()
     ex["survey_8d"] = {"steps": S, "warmup": GRAPH_CHUNK, "repeats": 5, "statistic": "median", **prot}
     return ex
 

@@ -315,6 +315,19 @@ int amenv_gaussian_act(const float* mean, const float* log_std, const float* low
 int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, int64_t n, float* mean_out,
                          float* value_out, void* stream);
 
+/* Closed-loop rollout in ONE launch (SB3 collect_rollouts, v2/rl_train.py:38-56, for n_steps steps): per step
+ *   obs_t -> actor / critic MLPs ([128, 64, 64] tanh; bf16 matrix cores, fp32 accumulate) -> a_t = mean + exp(log_std) z  (Philox keyed
+ *   by (seed, global env id, draw0 + t) as amenv_gaussian_act) -> clip to the action box -> env step (as amenv_step, auto-reset included).
+ * State, per-lane constants and the policy weights stay in registers between steps.  Built for the fp32 6-rotor vehicle with the z,x,x
+ * arm (obs_dim 29, act_dim 7; the lane-team layout); other configurations return AMENV_ERR_INVALID.  An opt-in ROLLOUT mode: bf16
+ * rounding perturbs the action means by ~1e-2 of their scale; log-probs are those of the samples under the means actually used.
+ *   flat_params  fp32 policy parameters in SB3 state-dict order (see amenv_policy_forward)
+ *   obs          [n_steps + 1, N, 29] f32: row 0 <- observation at entry, row t + 1 <- after step t (post-reset for done envs)
+ *   actions      [n_steps, N, 7] f32 raw (unclipped) samples;  logp, values, rewards [n_steps, N] f32;  dones [n_steps, N] u8
+ *   info_bits    [n_steps, N] u32 or NULL;  terminal_obs [n_steps, N, 29] f32 or NULL (rows written only where dones != 0) */
+int amenv_rollout_policy(amenv* env, int32_t n_steps, const float* flat_params, uint64_t seed, uint32_t draw0, float* obs, float* actions,
+                         float* logp, float* values, float* rewards, uint8_t* dones, uint32_t* info_bits, float* terminal_obs, void* stream);
+
 /* The part of SB3's PPO.train between the network outputs and the backward pass, fused (three launches instead of ~60 torch
  * kernels): per-minibatch advantage normalisation (mean, unbiased std, eps 1e-8), Gaussian log-prob of `actions` under
  * (mean, log_std), ratio to old_logp, clipped surrogate, value MSE, entropy bonus -- and the gradient of

@@ -77,6 +77,7 @@ SYMBOLS = {
     "amenv_step": (C.c_int, [_P] * 10),
     "amenv_step_timed": (C.c_int, [_P] * 10 + [C.POINTER(C.c_float)]),
     "amenv_rollout": (C.c_int, [_P, C.c_int32] + [_P] * 6),
+    "amenv_rollout_policy": (C.c_int, [_P, C.c_int32, _P, C.c_uint64, C.c_uint32] + [_P] * 9),
     "amenv_get_state": (C.c_int, [_P] * 4),
     "amenv_set_state": (C.c_int, [_P] * 4),
     "amenv_observe": (C.c_int, [_P, _P, _P]),

@@ -16,6 +16,7 @@
 
 #include "amenv_kernels.hpp"
 #include "amenv_team.hpp"
+#include "amenv_team_policy.hpp"
 #include "amenv_obsnorm.hpp"
 #include "amenv_policy.hpp"
 #include "amenv_train.hpp"
@@ -36,6 +37,8 @@ struct amenv {
   bool pwave = false;              // rigid vehicles at small batches: second wave per tile computes the reset RNG words (step_kernel_pw)
   bool team = false;               // lane-team kernel (16 lanes per env): fp32 z,x,x-arm vehicle in the latency regime (amenv_team.hpp)
   float* team_consts = nullptr;    // [kTeamConsts][16] per-lane constants of the team kernel
+  bool team_ok = false;            // the configuration has a team kernel (fp32, 6 rotors, z,x,x arm): constants are allocated
+  uint32_t* pol_pack = nullptr;    // amenv_rollout_policy: policy parameters as MFMA fragments (re-packed on every call)
   uint64_t steps = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // amenv_step_timed only
   std::string err;
@@ -568,8 +571,15 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     amenv_destroy(e);
     return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is built for the fp32 6-rotor vehicle with the z,x,x arm");
   }
-  if (e->team) {
-    e->arm2w = false;
+  e->team_ok = cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes &&
+               !is_v1(cfg) && cfg->task.num_waypoints == 1;
+  if (e->team) e->arm2w = false;
+  if (e->team_ok) {
+    if ((s = hipMalloc((void**)&e->pol_pack, size_t(kPolPackWords) * sizeof(uint32_t))) != hipSuccess) {
+      std::string msg = std::string("amenv_create: policy pack: ") + hipGetErrorString(s);
+      amenv_destroy(e);
+      return fail(nullptr, AMENV_ERR_ALLOC, msg);
+    }
     const std::vector<float> tc = team_const_table(*cfg);
     if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(float))) != hipSuccess ||
         (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -589,6 +599,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                 is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), cfg->vehicle.n_joints ? "v2+arm3" : (is_v1(cfg) ? "v1" : "v2"), e->block);
   e->obs_dim = obs_dim_of(cfg);
+  e->act_dim = act_dim_of(cfg);
   e->kname = buf;
   *out = e;
   return AMENV_OK;
@@ -601,6 +612,7 @@ int amenv_destroy(amenv* e) {
     if (e->blob) (void)hipFree(e->blob);
     if (e->stats) (void)hipFree(e->stats);
     if (e->team_consts) (void)hipFree(e->team_consts);
+    if (e->pol_pack) (void)hipFree(e->pol_pack);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
   }
@@ -686,6 +698,36 @@ int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, v
   hipStream_t s = (hipStream_t)stream;
   hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, n_steps, s) : dispatch_step<float>(*e, io, n_steps, s);
   AMENV_HIP(e, st);
+  e->steps += uint64_t(e->cfg.num_envs) * uint64_t(n_steps);
+  return AMENV_OK;
+}
+
+int amenv_rollout_policy(amenv* e, int32_t n_steps, const float* flat_params, uint64_t seed, uint32_t draw0, float* obs, float* actions, float* logp,
+                         float* values, float* rewards, uint8_t* dones, uint32_t* info_bits, float* terminal_obs, void* stream) {
+  if (!e) return AMENV_ERR_INVALID;
+  if (!e->team_ok) return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: built for the fp32 6-rotor vehicle with the z,x,x arm (v2 task, 1 waypoint)");
+  if (n_steps <= 0 || !flat_params || !obs || !actions || !logp || !values || !rewards || !dones)
+    return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: n_steps must be > 0 and flat_params / obs / actions / logp / values / rewards / dones non-NULL");
+  DeviceGuard g(e->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int obs_dim = e->obs_dim, act_dim = e->act_dim;   // 29, 7
+  // parameters -> bf16 MFMA fragments + per-lane action constants (they change every PPO iteration): a tiny kernel in front, no host sync
+  const int pack_threads = 4 * (kPolFrags + kPolBias) * 64 + 64;
+  hipLaunchKernelGGL(policy_pack_kernel, dim3((pack_threads + 255) / 256), dim3(256), 0, s, flat_params, obs_dim, act_dim, e->pol_pack);
+  PolicyIO io;
+  io.pack = reinterpret_cast<const uint4*>(e->pol_pack);
+  io.seed_lo = uint32_t(seed); io.seed_hi = uint32_t(seed >> 32); io.draw0 = draw0;
+  io.obs = obs; io.actions = actions; io.logp = logp; io.values = values; io.rewards = rewards; io.dones = dones; io.info = info_bits;
+  io.terminal_obs = terminal_obs;
+  const TeamParams TP = make_team(*e);
+  // one 16-env workgroup per CU up to 4096 envs; above that two wavefronts per SIMD pay (measured on MI355X: 32768 envs)
+  const char* occ_env = std::getenv("AMENV_POLICY_OCC");   // bench / A-B only (tools/): 1 or 2
+  const int occ = occ_env ? std::atoi(occ_env) : (e->cfg.num_envs <= 8192 ? 1 : 2);
+  if (occ == 1) hipLaunchKernelGGL((rollout_policy_kernel_team<6, 1>), dim3(e->n_tiles * 4), dim3(256), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io,
+                                   e->stats, make_cold(*e), TP);
+  else hipLaunchKernelGGL((rollout_policy_kernel_team<6, 2>), dim3(e->n_tiles * 4), dim3(256), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io, e->stats,
+                          make_cold(*e), TP);
+  AMENV_HIP(e, hipGetLastError());
   e->steps += uint64_t(e->cfg.num_envs) * uint64_t(n_steps);
   return AMENV_OK;
 }

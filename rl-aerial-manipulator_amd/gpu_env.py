@@ -166,6 +166,26 @@ class GpuWaypointEnv:
                                            self._stream()), "amenv_rollout")
         return out
 
+    def rollout_policy(self, flat_params, n_steps, seed, draw0, obs, actions, logp, values, rewards, dones, info_bits=None, terminal_obs=None):
+        """T closed-loop steps in ONE launch: obs -> actor / critic MLPs (bf16 matrix cores) -> Gaussian sample -> clip -> env step,
+        writing SB3's rollout-buffer rows: obs [T+1,N,OD] (row 0 = observation at entry), actions [T,N,A] raw samples, logp / values /
+        rewards [T,N] f32, dones [T,N] u8, optionally info_bits [T,N] i32 and terminal_obs [T,N,OD].  Caller-owned contiguous tensors on
+        this env's device.  Built for the fp32 hexacopter + arm (include/amenv.h amenv_rollout_policy)."""
+        T, n = int(n_steps), self.num_envs
+        want = {"obs": ((T + 1, n, self.obs_dim), torch.float32), "actions": ((T, n, self.act_dim), torch.float32), "logp": ((T, n), torch.float32),
+                "values": ((T, n), torch.float32), "rewards": ((T, n), torch.float32), "dones": ((T, n), torch.uint8)}
+        got = {"obs": obs, "actions": actions, "logp": logp, "values": values, "rewards": rewards, "dones": dones}
+        for k, (shape, dt) in want.items():
+            t = got[k]
+            if t.device != self.device or t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
+                raise L.AmenvError(f"rollout_policy: {k} must be a contiguous {dt} tensor of shape {shape} on {self.device}")
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        fp = flat_params.detach()
+        if fp.device != self.device or fp.dtype != torch.float32 or not fp.is_contiguous():
+            raise L.AmenvError("rollout_policy: flat_params must be a contiguous fp32 tensor on this env's device")
+        self._check(self.lib.amenv_rollout_policy(self._h, T, p(fp), int(seed) & 0xFFFFFFFFFFFFFFFF, int(draw0) & 0xFFFFFFFF, p(obs), p(actions), p(logp),
+                                                  p(values), p(rewards), p(dones), p(info_bits), p(terminal_obs), self._stream()), "amenv_rollout_policy")
+
     def observe(self):
         o = torch.empty(self.num_envs, self.obs_dim, dtype=torch.float32, device=self.device)
         self._check(self.lib.amenv_observe(self._h, C.c_void_p(o.data_ptr()), self._stream()), "amenv_observe")

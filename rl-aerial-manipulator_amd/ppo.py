@@ -437,7 +437,7 @@ class PPO:
 
     def __init__(self, env, policy=None, learning_rate=2e-4, n_steps=2048, batch_size=128, n_epochs=12, gamma=0.995,
                  gae_lambda=0.9, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5, normalize_advantage=True,
-                 net_arch=(128, 64, 64), seed=0, obs_normalizer=None, bootstrap_truncated=True, dist=None, use_graph=None):
+                 net_arch=(128, 64, 64), seed=0, obs_normalizer=None, bootstrap_truncated=True, dist=None, use_graph=None, fused_rollout=False):
         if env.state_dtype != torch.float32:
             raise L.AmenvError("PPO needs the fp32 environment")
         self.env, self.dist = env, dist
@@ -470,6 +470,11 @@ class PPO:
         self._gen.manual_seed(self.seed * 1000003 + int(getattr(env.cfg, "env_id_offset", 0)))
         self._draw = 0
         self._started = False
+        # opt-in: the whole rollout (policy MLPs on the bf16 matrix cores, sampling, clip, env step) in ONE launch -- amenv_rollout_policy
+        self.fused_rollout = bool(fused_rollout)
+        if self.fused_rollout and obs_normalizer is not None:
+            raise L.AmenvError("fused_rollout does not go through an observation normaliser")
+        self._term_obs = self._info = None
         self.num_timesteps = 0
         self.log = []
 
@@ -487,6 +492,8 @@ class PPO:
     def collect_rollouts(self):
         """SB3 `OnPolicyAlgorithm.collect_rollouts`: n_steps steps of every env into the buffer, then GAE."""
         b, env, pol = self.buffer, self.env, self.policy
+        if self.fused_rollout:
+            return self._collect_rollouts_fused()
         if not self._started:
             self._first_obs()
         else:
@@ -514,6 +521,34 @@ class PPO:
         b.last_values.copy_(pol.critic(b.obs[self.n_steps]))
         compute_gae(b, self.gamma, self.gae_lambda)
         self.num_timesteps += self.n_steps * env.num_envs * self.world
+        return b
+
+    def _collect_rollouts_fused(self):
+        """collect_rollouts as ONE kernel launch (csrc/amenv_team_policy.hpp): n_steps x (actor / critic forward in bf16 on the matrix
+        cores -> Gaussian sample -> clip -> env step) with state, constants and weights in registers; the buffer rows are written by the
+        kernel.  What stays on the host side of the launch: the time-limit bootstrap reward += gamma V(terminal_observation) (one critic
+        call over the truncated entries), V of the last observation, GAE.  The rollout policy is the bf16 rounding of the fp32 policy the
+        update differentiates (means differ by ~1e-2 of their scale): PPO's clipped ratio absorbs that; log-probs are those of the
+        samples under the means the kernel used."""
+        b, env, pol, T = self.buffer, self.env, self.policy, self.n_steps
+        if not self._started:
+            env.reset()
+            self._started = True
+        if self._term_obs is None:
+            self._term_obs = torch.zeros(T, env.num_envs, env.obs_dim, dtype=torch.float32, device=self.device)
+            self._info = torch.zeros(T, env.num_envs, dtype=torch.int32, device=self.device)
+        env.rollout_policy(pol.flat_param, T, self.seed, self._draw, b.obs, b.actions, b.logp, b.values, b.rewards, b.dones, self._info,
+                           self._term_obs if self.bootstrap_truncated else None)
+        self._draw += T
+        if self.bootstrap_truncated:
+            trunc = ((self._info & (L.INFO_TERMINATED | L.INFO_TRUNCATED)) == L.INFO_TRUNCATED) & (b.dones != 0)
+            idx = trunc.reshape(-1).nonzero().reshape(-1)
+            if idx.numel():
+                v = pol.critic(self._term_obs.reshape(-1, env.obs_dim).index_select(0, idx))
+                b.rewards.reshape(-1).index_add_(0, idx, self.gamma * v)
+        b.last_values.copy_(pol.critic(b.obs[T]))
+        compute_gae(b, self.gamma, self.gae_lambda)
+        self.num_timesteps += T * env.num_envs * self.world
         return b
 
     # ---- update ---------------------------------------------------------------------------------

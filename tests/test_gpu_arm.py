@@ -362,3 +362,61 @@ def test_team_rollout_kernel_equals_team_steps():
     # outputs are optional
     e1.rollout(acts[:5], want_obs=False, want_flags=False)
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("n", [300, 4096])
+def test_closed_loop_policy_rollout_kernel(n):
+    """amenv_rollout_policy: T closed-loop steps in one launch (bf16-MFMA actor / critic, Gaussian sampling, clip, team env step).
+    The env part is checked EXACTLY by replaying the recorded (clipped) actions through amenv_step on a second env; the policy part against
+    the fp32 torch modules on the recorded observations (bf16 tolerance: means / values within 3e-2 of their scale); the samples
+    statistically (z = (a - mean) / std ~ N(0, 1), log-probs consistent with the samples)."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    T = 96
+    torch.manual_seed(5)
+    pol = amd.ActorCritic(29, 7).cuda().flatten_()
+    with torch.no_grad():
+        pol.log_std.data.fill_(-1.2)
+        for m in (pol.action_net,):                              # a less timid head than SB3's 0.01-gain init: means of O(0.3)
+            m.weight.mul_(30.0)
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="team", max_episode_steps=60)
+    ref = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="team", max_episode_steps=60)
+    o0 = env.reset().clone(); ref.reset()
+    dev = env.device
+    obs = torch.zeros(T + 1, n, 29, device=dev); acts = torch.zeros(T, n, 7, device=dev)
+    logp = torch.zeros(T, n, device=dev); vals = torch.zeros(T, n, device=dev); rew = torch.zeros(T, n, device=dev)
+    dones = torch.zeros(T, n, dtype=torch.uint8, device=dev); info = torch.zeros(T, n, dtype=torch.int32, device=dev)
+    tobs = torch.full((T, n, 29), float("nan"), device=dev)
+    env.rollout_policy(pol.flat_param, T, seed=77, draw0=5, obs=obs, actions=acts, logp=logp, values=vals, rewards=rew, dones=dones, info_bits=info, terminal_obs=tobs)
+    torch.cuda.synchronize()
+    assert float((obs[0] - o0).abs().max()) < 1e-6               # (forward kinematics of the home pose vs the reset path's constant offset)
+    lo, hi = pol.action_low, pol.action_high
+    # (1) env part: replay the clipped actions step by step on the second env -> identical observations / rewards / flags
+    for t in range(T):
+        o, r, d, i = ref.step(torch.max(torch.min(acts[t], hi), lo))
+        assert torch.equal(o, obs[t + 1]) and torch.equal(r, rew[t]) and torch.equal(d, dones[t]) and torch.equal(i, info[t]), t
+        dn = d.bool()
+        if bool(dn.any()):
+            assert torch.equal(ref.terminal_obs[dn], tobs[t][dn])
+    f1, i1 = env.get_state(); f2, i2 = ref.get_state()
+    assert torch.equal(f1, f2) and torch.equal(i1, i2) and env.stats()["episodes"] == ref.stats()["episodes"] == int(dones.sum()) > n // 2
+    assert bool(torch.isnan(tobs[~dones.bool()]).all())          # terminal rows are written only where an episode ended
+    # (2) policy part vs the fp32 modules on the recorded observations
+    with torch.no_grad():
+        flat = obs[:T].reshape(T * n, 29)
+        mean32 = pol.action_net(pol.mlp_extractor.policy_net(flat)); v32 = pol.value_net(pol.mlp_extractor.value_net(flat)).reshape(-1)
+    std = torch.exp(pol.log_std.detach())
+    assert float((vals.reshape(-1) - v32).abs().max()) < 3e-2 * max(1.0, float(v32.abs().max()))
+    z = (acts.reshape(T * n, 7) - mean32) / std                  # the noise the kernel drew, up to the bf16 error of its means
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.03 and float(z.abs().max()) < 6.5
+    zc = torch.corrcoef(z[: 50000].T)
+    assert float((zc - torch.eye(7, device=dev)).abs().max()) < 0.03                   # independent components
+    lp32 = (-0.5 * z * z - pol.log_std.detach() - 0.9189385332).sum(1)
+    assert float((logp.reshape(-1) - lp32).abs().max()) < 0.5 and float((logp.reshape(-1) - lp32).abs().mean()) < 0.05
+    # different draw index -> different noise; same call again from the same state -> identical (deterministic)
+    env2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="team", max_episode_steps=60); env2.reset()
+    acts2 = torch.zeros_like(acts)
+    env2.rollout_policy(pol.flat_param, T, seed=77, draw0=5, obs=torch.zeros_like(obs), actions=acts2, logp=torch.zeros_like(logp), values=torch.zeros_like(vals),
+                        rewards=torch.zeros_like(rew), dones=torch.zeros_like(dones))
+    assert torch.equal(acts2, acts)
+    env.close(); ref.close(); env2.close()

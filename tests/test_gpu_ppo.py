@@ -415,3 +415,34 @@ def test_checkpoint_cadence_and_full_resume(tmp_path):
     assert res.num_timesteps == 6 * per_iter and all(math.isfinite(v) for v in res.log[-1].values())
     assert float(res.optimizer.state[res._leaf]["step"]) == 6 * 2 * 4
     env.close(); env2.close()
+
+
+def test_fused_rollout_feeds_the_update():
+    """PPO(fused_rollout=True): collect_rollouts is ONE launch of amenv_rollout_policy (bf16 policy on the matrix cores + env steps); the
+    buffer it fills is consistent with the fp32 policy the update differentiates (values / log-probs within bf16 tolerance, ratio ~ 1
+    at the first minibatch), GAE matches the SB3 restatement, learn() runs and moves the parameters."""
+    from oracle import oracle as O
+    env = amd.GpuWaypointEnv(2048, vehicle="hexa_arm", seed=5, max_episode_steps=30)      # truncations inside the rollout
+    algo = PPO(env, n_steps=64, batch_size=16384, n_epochs=2, seed=3, fused_rollout=True)
+    with torch.no_grad():
+        algo.policy.log_std.data.fill_(-1.0)
+    b = algo.collect_rollouts()
+    T, n = 64, 2048
+    N = T * n
+    with torch.no_grad():
+        values, logp, _ = algo.policy.evaluate_actions(b.obs[:T].reshape(N, -1), b.actions.reshape(N, -1))
+    assert float((values - b.values.reshape(N)).abs().max()) < 3e-2 * max(1.0, float(values.abs().max()))
+    assert float((logp - b.logp.reshape(N)).abs().mean()) < 0.05 and float((logp - b.logp.reshape(N)).abs().max()) < 0.6
+    d = b.dones.bool()
+    assert int(d[30].sum()) > n // 2 and algo._draw == T
+    # rewards at truncated entries carry gamma * V(terminal_observation); GAE over the buffer as SB3 computes it
+    r, v, dn, lv = (x.cpu().numpy() for x in (b.rewards, b.values, b.dones, b.last_values))
+    adv_ref, _ = O.gae_reference(r, v, dn, lv, 0.995, 0.9)
+    assert (np.abs(b.advantages.cpu().numpy() - adv_ref) / (1.0 + gae_magnitude(r, v, dn, lv))).max() < 1e-6
+    p0 = algo.policy.flat_param.detach().clone()
+    rec = algo.train()
+    assert all(math.isfinite(x) for x in rec.values()) and rec["clip_fraction"] < 0.5
+    algo.learn(2 * N)
+    assert algo.num_timesteps == 3 * N and float((algo.policy.flat_param.detach() - p0).abs().max()) > 1e-5
+    assert all(math.isfinite(x) for rec in algo.log for x in rec.values())
+    env.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 GPU pass A: parity tests, the driver's bench command, kernel-trace profile of the same command, PMC traffic
 set -o pipefail
-R=$PWD; O=$R/gpurun_out/r02a; mkdir -p $O; export TMPDIR=/tmp
+R=$PWD; O=$R/gpurun_out/r02d; mkdir -p $O; export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $O/pytest_gpu.log
 tail -5 $O/pytest_gpu.log
 python bench.py --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err && tail -c 600 $O/bench_driver.json &&

@@ -1,30 +1,26 @@
 #!/bin/bash
-# team-kernel iteration: correctness, stamp profile, timing
 set -o pipefail
 R=$PWD; O=$R/gpurun_out/team; mkdir -p $O; export TMPDIR=/tmp
-python -m pytest tests/test_gpu_arm.py -m gpu -x -q -p no:cacheprovider -k "team or closed_loop or forward_kin" > $O/pytest_team.log 2>&1; echo "pytest exit $?"; tail -4 $O/pytest_team.log
-AMENV_LIB=$R/tools/micro/libamenv_stamps.so python tools/stamp_profile.py --envs 4096 --vehicle hexa_arm --kernel team 2>/dev/null | head -9
-for K in team helper; do
-  python bench.py --kernel $K --no-cpu-baseline --no-extras > $O/bench_$K.json 2> $O/bench_$K.err; python -c "
-import json,sys
-d=json.load(open('$O/bench_$K.json')); print('$K', '%.4g' % d['value'], 'dev us/step %.3f' % (d['device_ms_per_step']*1e3), 'isolated min %.2f' % d['roofline']['kernel_us_isolated_min'])"
-done
-python - <<'PY'
-import torch, time
+python -m pytest tests/test_gpu_arm.py -m gpu -x -q -p no:cacheprovider -k "policy_rollout" > $O/pytest_team.log 2>&1; echo "pytest exit $?"; grep -E "^E|passed|failed" $O/pytest_team.log | head -20
+for OCC in 1 2; do AMENV_POLICY_OCC=$OCC python - <<'PY'
+import torch, os
 import rl_aerial_manipulator_amd as amd
-for kern in ("team", "lane"):
-    n, T = 4096, 64
-    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=0, kernel=kern)
+for n in (4096, 8192, 32768):
+    T = 64
+    pol = amd.ActorCritic(29, 7).cuda().flatten_()
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=0)
     env.reset()
-    g = torch.Generator(device="cuda").manual_seed(1)
-    a = (torch.randn(T, n, 7, device="cuda", generator=g) * 0.1); a[..., 0] += 1; a[..., 4:] *= 3; a = a.clamp(-1, 2).contiguous()
-    for want in (True, False):
-        env.rollout(a, want_obs=want)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(8): env.rollout(a, want_obs=want)
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / (8 * T)
-        print(f"rollout {kern} obs={want}: {us:.3f} us/step  {n / us * 1e6:.4g} env-steps/s")
+    dev = env.device
+    obs = torch.zeros(T + 1, n, 29, device=dev); acts = torch.zeros(T, n, 7, device=dev)
+    logp = torch.zeros(T, n, device=dev); vals = torch.zeros(T, n, device=dev); rew = torch.zeros(T, n, device=dev)
+    dones = torch.zeros(T, n, dtype=torch.uint8, device=dev)
+    run = lambda: env.rollout_policy(pol.flat_param, T, seed=1, draw0=0, obs=obs, actions=acts, logp=logp, values=vals, rewards=rew, dones=dones)
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (8 * T)
+    print(f"OCC={os.environ['AMENV_POLICY_OCC']} closed-loop policy rollout n={n}: {us:.3f} us/step  {n / us * 1e6:.4g} env-steps/s")
 PY
+done
