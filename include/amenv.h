@@ -274,6 +274,10 @@ int amenv_ee_position(amenv* env, float* ee_out, void* stream);
 /* Copy the running totals to *host_out (synchronises the stream); optionally zero them. */
 int amenv_stats_read(amenv* env, amenv_stats* host_out, int reset, void* stream);
 
+/* Bench / profiling only: copy `bytes` (a multiple of 16) with 4 or 16 bytes per lane -- a dispatch of known traffic in the access
+ * pattern of the kernel under test, for calibrating the PMC counters FETCH_SIZE / WRITE_SIZE (tools/pmc_traffic.py). */
+int amenv_calibration_copy(const void* src, void* dst, size_t bytes, int32_t bytes_per_lane, void* stream);
+
 /* Name, VGPR count etc. of the step kernel chosen for this handle (for bench/profiles). */
 const char* amenv_kernel_name(const amenv* env);
 

@@ -84,6 +84,7 @@ SYMBOLS = {
     "amenv_ee_position": (C.c_int, [_P, _P, _P]),
     "amenv_stats_read": (C.c_int, [_P, C.POINTER(Stats), C.c_int, _P]),
     "amenv_kernel_name": (C.c_char_p, [_P]),
+    "amenv_calibration_copy": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, _P]),
     "amenv_obsnorm_create": (C.c_int, [C.c_int32, C.c_int, C.POINTER(_P)]),
     "amenv_obsnorm_destroy": (C.c_int, [_P]),
     "amenv_obsnorm_update": (C.c_int, [_P, _P, C.c_int64, _P]),

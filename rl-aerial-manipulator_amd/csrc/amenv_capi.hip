@@ -444,6 +444,11 @@ hipError_t launch_transpose(const amenv& e, void* f, int32_t* i, int to_api, hip
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+template <typename V>
+__global__ void calibration_copy_kernel(const V* __restrict__ src, V* __restrict__ dst, size_t n) {
+  for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -593,7 +598,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                               cfg->dtype == AMENV_F64 ? "double" : "float",
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
-  else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave)");
+  else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6,v2+arm3> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave)");
   else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
@@ -916,6 +921,17 @@ int amenv_ppo_loss_grad(const float* mean, const float* value, const float* log_
     default: return AMENV_ERR_INVALID;
   }
   hipLaunchKernelGGL(ppo_finalize, dim3(1), dim3(64), 0, s, (const float*)part, blocks, (int)act_dim, (int64_t)n, log_std, ent_coef, d_log_std, stats4);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+// Bench / profiling utility: a copy of known size with a chosen access width per lane, so that the PMC traffic counters (FETCH_SIZE,
+// WRITE_SIZE) can be calibrated on the access pattern of the kernel under test (16 B per lane: one-lane-per-env kernels; 4 B per lane:
+// lane-team kernels) -- /opt/skills/guides/MI355X_MICROARCH.md, HBM section.
+int amenv_calibration_copy(const void* src, void* dst, size_t bytes, int32_t bytes_per_lane, void* stream) {
+  if (!src || !dst || (bytes_per_lane != 4 && bytes_per_lane != 16) || bytes % 16) return AMENV_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (bytes_per_lane == 4) hipLaunchKernelGGL((calibration_copy_kernel<float>), dim3(2048), dim3(256), 0, s, (const float*)src, (float*)dst, bytes / 4);
+  else hipLaunchKernelGGL((calibration_copy_kernel<float4>), dim3(2048), dim3(256), 0, s, (const float4*)src, (float4*)dst, bytes / 16);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

@@ -249,6 +249,11 @@ __device__ __forceinline__ float team_tool_offset(const TeamParams& P, const flo
   return fma_(2.0f, cross_c(qv, fma_(-qw, p, cross_c(qv, p))), p);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its own L2).  A team wavefront touches
+// 64 B of every state group; with the identity mapping the two halves of each 128-B line would be fetched by two different XCDs.
+// Blocks that share an XCD therefore take CONSECUTIVE 4-env groups (speed only: any mapping is correct).  gridDim.x is a multiple of 64.
+__device__ __forceinline__ int team_group_of_block(int b, int nblocks) { return (b & 7) * (nblocks >> 3) + (b >> 3); }
+
 // ---- one env row's registers, and the per-lane role of a lane in its team -------------------------------------------------------------
 struct TeamEnv {
   TeamState y;                                   // dynamic state (component per lane, replicated in the four quads)
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, 
   AMENV_STAMP(0);
   TeamLane L;
   L.init(P);
-  const int i = int(blockIdx.x) * 4 + (L.lane >> 4);        // env of this row
+  const int i = team_group_of_block(int(blockIdx.x), int(gridDim.x)) * 4 + (L.lane >> 4);   // env of this row
   const bool active = i < n_envs;
   const int ia = active ? i : n_envs - 1;                   // rows past the end redo the last env's arithmetic (their outputs are masked)
   char* tile = static_cast<char*>(blob) + size_t(i >> 6) * tile_bytes;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(64) void rollout_kernel_team(void* __restrict__ blo
   constexpr int AD = 7, OD = 29;
   TeamLane L;
   L.init(P);
-  const int i = int(blockIdx.x) * 4 + (L.lane >> 4);
+  const int i = team_group_of_block(int(blockIdx.x), int(gridDim.x)) * 4 + (L.lane >> 4);
   const bool active = i < n_envs;
   const int ia = active ? i : n_envs - 1;
   char* tile = static_cast<char*>(blob) + size_t(i >> 6) * tile_bytes;

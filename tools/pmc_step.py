@@ -28,11 +28,14 @@ ring = ring.clamp(min=-1, max=2).contiguous()
 for t in range(a.steps):
     env.step(ring[t % 16])
 if a.calibrate:
-    # a copy of known size done by an ELEMENTWISE KERNEL (16 B per lane): a plain Tensor.copy_ may go through the SDMA engine or a blit
-    # kernel of another name and then the counter pass holds no dispatch to calibrate on
+    # copies of known size (256 MiB) in the access pattern of the kernel under test: 16 B per lane (one-lane-per-env kernels) and 4 B per
+    # lane (lane-team kernels), through the library's own calibration kernel so that the dispatch is found by name
+    import ctypes as C
     src = torch.empty(256 * 1024 * 1024 // 4, dtype=torch.float32, device="cuda").normal_()
     dst = torch.empty_like(src)
-    for _ in range(3):
-        torch.mul(src, 1.0, out=dst)
+    for width in (16, 4):
+        for _ in range(3):
+            rc = env.lib.amenv_calibration_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel() * 4, width, None)
+            assert rc == 0
 torch.cuda.synchronize()
 print("done", env.kernel_name, env.stats()["episodes"])

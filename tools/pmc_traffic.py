@@ -32,21 +32,27 @@ def collect(counter, envs, vehicle, outdir):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
                 acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-    step = [v for k, v in acc.items() if "step_kernel" in k]
+    step = [(k, v) for k, v in acc.items() if "step_kernel" in k]
     mean = lambda xs: sum(xs) / len(xs)
-    # the calibration dispatch is selected BY NAME: torch's elementwise kernel of `torch.mul(src, 1.0, out=dst)` over 256 MiB (pmc_step.py);
-    # among the elementwise dispatches of the run it is the only one of that size
-    cal = max((max(v) for k, v in acc.items() if "elementwise_kernel" in k), default=None)
-    return mean(step[0][20:]), cal
+    # calibration dispatches are selected BY NAME: the library's calibration_copy_kernel<float4> (16 B per lane) / <float> (4 B per lane)
+    cal = {w: next((mean(v) for k, v in acc.items() if "calibration_copy_kernel" in k and (("float4" in k or "HIP_vector_type" in k) == (w == 16))), None) for w in (16, 4)}
+    name, vals = step[0]
+    return mean(vals[20:]), cal, ("team" in name)
 
 
 CAL_KIB = 256 * 1024   # the calibration copy reads and writes 256 MiB
 
 
-def calibration_ok(f_cal, w_cal):
-    """FETCH_SIZE must read half the copy (the gfx950 16-B/lane correction), WRITE_SIZE all of it, both within 5 %."""
-    return f_cal is not None and w_cal is not None and abs(2.0 * f_cal / CAL_KIB - 1.0) < 0.05 and abs(w_cal / CAL_KIB - 1.0) < 0.05
-
+def factor(kib, what):
+    """counter units -> bytes for this access width, from the calibration copy (must land within 5 % of a simple ratio: 1 or 2)"""
+    if kib is None or kib <= 0:
+        return None
+    f = CAL_KIB / kib
+    for want in (1.0, 2.0):
+        if abs(f / want - 1.0) < 0.05:
+            return f
+    print(f"calibration {what}: the 256 MiB copy reads as {kib} KiB (factor {f:.3f}): not a clean 1x / 2x", flush=True)
+    return None
 
 
 def main():
@@ -63,19 +69,21 @@ def main():
     path = os.path.join(a.out, "traffic.json")
     res = json.load(open(path)) if os.path.exists(path) else {}    # merge: one invocation per vehicle
     for n in a.envs:
-        f_kib, f_cal = collect("FETCH_SIZE", n, a.vehicle, a.out)
-        w_kib, w_cal = collect("WRITE_SIZE", n, a.vehicle, a.out)
-        fetch = 2.0 * f_kib * 1024.0   # gfx950 correction for 16-B/lane coalesced reads
-        write = w_kib * 1024.0
-        if not calibration_ok(f_cal, w_cal):   # never record a traffic figure whose unit / correction check failed
-            print(f"N={n}: calibration copy reads fetch {f_cal} KiB (want ~{CAL_KIB // 2}) write {w_cal} KiB (want ~{CAL_KIB}): entry NOT written", flush=True)
-            res.pop(f"{a.vehicle}_{n}_f32", None)
+        f_kib, f_cal, team = collect("FETCH_SIZE", n, a.vehicle, a.out)
+        w_kib, w_cal, _ = collect("WRITE_SIZE", n, a.vehicle, a.out)
+        width = 4 if team else 16     # access width of the kernel under test: lane-team kernels move dwords, the others 16 B per lane
+        kf, kw = factor(f_cal[width], f"FETCH_SIZE @{width} B/lane"), factor(w_cal[width], f"WRITE_SIZE @{width} B/lane")
+        key = f"{a.vehicle}_{n}_f32"
+        if kf is None or kw is None:   # never record a traffic figure whose unit / correction check failed
+            print(f"N={n}: calibration failed ({f_cal}, {w_cal}): entry NOT written", flush=True)
+            res.pop(key, None)
             continue
-        res[f"{a.vehicle}_{n}_f32"] = dict(fetch_size_kib_raw=f_kib, write_size_kib_raw=w_kib, fetch_bytes_per_launch=fetch,
-                                          write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
-                                          calibration_copy_256MiB=dict(fetch_kib_raw=f_cal, write_kib_raw=w_cal))
-        print(f"N={n:8d}: FETCH_SIZE {f_kib:10.1f} KiB (x2 -> {fetch/1e6:8.3f} MB)  WRITE_SIZE {w_kib:10.1f} KiB ({write/1e6:8.3f} MB)  "
-              f"per env-step {(fetch + write) / n:7.1f} B   calibration copy(256 MiB): fetch {f_cal} KiB write {w_cal} KiB", flush=True)
+        fetch, write = kf * f_kib * 1024.0, kw * w_kib * 1024.0
+        res[key] = dict(fetch_size_kib_raw=f_kib, write_size_kib_raw=w_kib, access_bytes_per_lane=width, fetch_factor=kf, write_factor=kw,
+                        fetch_bytes_per_launch=fetch, write_bytes_per_launch=write, hbm_bytes_per_launch=fetch + write,
+                        calibration_copy_256MiB=dict(fetch_kib_raw=f_cal, write_kib_raw=w_cal))
+        print(f"N={n:8d} ({width} B/lane): FETCH_SIZE {f_kib:10.1f} KiB x{kf:.2f} -> {fetch/1e6:8.3f} MB   WRITE_SIZE {w_kib:10.1f} KiB x{kw:.2f} -> {write/1e6:8.3f} MB   "
+              f"per env-step {(fetch + write) / n:7.1f} B   calibration copies (256 MiB): fetch {f_cal} KiB, write {w_cal} KiB", flush=True)
     with open(path, "w") as f:
         json.dump(res, f, indent=1)
 
