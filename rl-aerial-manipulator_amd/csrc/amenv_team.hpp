@@ -297,19 +297,19 @@ __device__ __forceinline__ void team_load(const char* tile, int i, const TeamLan
   E.step = iv.x; E.counter = iv.y; E.flags = iv.z; E.episode = iv.w;
 }
 
-// quad b writes group b (p|yaw, v|last_distance, q, w|return), then joints (quads 0, 1), the int plane (quad 2) and, after a reset, the waypoint
-__device__ __forceinline__ void team_store(char* tile, int i, const TeamLane& L, const TeamEnv& E, bool store_waypoint) {
+// Two unconditional stores: (1) quad b writes group b (p|yaw, v|last_distance, q, w|return); (2) quad 0 the joint angles, quad 1 the
+// joint rates, quad 2 the int plane, quad 3 the waypoint group (rewritten with its unchanged value between resets) -- per-lane
+// offsets, no divergent store.
+__device__ __forceinline__ void team_store(char* tile, int i, const TeamLane& L, const TeamEnv& E) {
   const uint32_t eoff = uint32_t(i & 63) * 16u + uint32_t(L.cc) * 4u;
   const bool l3 = L.cc == 3;
   const float g0 = l3 ? E.final_yaw : E.y.P, g1 = l3 ? E.last_distance : E.y.V, g3 = l3 ? E.ep_return : E.y.W;
   const float sv = L.q0 ? g0 : (L.q1 ? g1 : (L.q2 ? E.y.Q : g3));
   *reinterpret_cast<float*>(tile + kIntBytes + uint32_t(L.bb) * 1024u + eoff) = sv;
-  if (L.bb < 2) *reinterpret_cast<float*>(tile + kIntBytes + uint32_t(5 + L.bb) * 1024u + eoff) = L.q0 ? E.y.TH : E.y.THD;
-  if (L.q2) {
-    const int ival = L.cc == 0 ? E.step : (L.cc == 1 ? E.counter : (L.cc == 2 ? E.flags : E.episode));
-    *(reinterpret_cast<int*>(tile) + (i & 63) * 4 + L.cc) = ival;
-  }
-  if (L.bb == 3 && store_waypoint) *reinterpret_cast<float*>(tile + kIntBytes + 4u * 1024u + eoff) = E.WP;
+  const int ival = L.cc == 0 ? E.step : (L.cc == 1 ? E.counter : (L.cc == 2 ? E.flags : E.episode));
+  const float s2 = L.q0 ? E.y.TH : (L.q1 ? E.y.THD : (L.q2 ? __int_as_float(ival) : E.WP));
+  const uint32_t off2 = L.q2 ? eoff : kIntBytes + (L.q0 ? 5u : (L.q1 ? 6u : 4u)) * 1024u + eoff;   // (the int plane has the same 16 B per env)
+  *reinterpret_cast<float*>(tile + off2) = s2;
 }
 
 struct TeamOut { float reward; uint32_t bits; float vA, vB, vC; bool ended; int ep_len; float ep_ret; };
@@ -427,20 +427,19 @@ __device__ __forceinline__ TeamOut team_advance(const TeamParams& P, const ColdP
   return o;
 }
 
+// per-step outputs; OPT = the caller may pass null pointers (rollout kernels), else all are present (step kernel: no pointer tests)
+template <bool OPT>
 __device__ __forceinline__ void team_store_outputs(const TeamLane& L, const TeamOut& o, uint32_t i, bool active, float* __restrict__ obs, float* __restrict__ reward_out,
                                                    uint8_t* __restrict__ done, uint32_t* __restrict__ info) {
-  if (active) {
-    const uint32_t row = i * 29u;
-    if (obs) {
-      if (L.okA) obs[row + L.offA] = o.vA;
-      if (L.okB) obs[row + L.offB] = o.vB;
-      if (L.okC) obs[row + L.offC] = o.vC;
-    }
-    if (L.lead) {
-      if (reward_out) reward_out[i] = o.reward;
-      if (done) done[i] = o.ended ? 1 : 0;
-      if (info) info[i] = o.bits;
-    }
+  const uint32_t row = i * 29u;
+  const bool ob = active && (!OPT || obs != nullptr);
+  if (ob && L.okA) obs[row + L.offA] = o.vA;
+  if (ob && L.okB) obs[row + L.offB] = o.vB;
+  if (ob && L.okC) obs[row + L.offC] = o.vC;
+  if (active && L.lead) {
+    if (!OPT || reward_out) reward_out[i] = o.reward;
+    if (!OPT || done) done[i] = o.ended ? 1 : 0;
+    if (!OPT || info) info[i] = o.bits;
   }
 }
 
@@ -473,8 +472,8 @@ __global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, 
   AMENV_STAMP(4);          // mixer + RK4 + forward kinematics + task step + episode end / reset
   accumulate_stats(tl.stats, int(blockIdx.x), o.bits, active && o.ended && L.lead, o.ep_len, o.ep_ret);
   AMENV_STAMP(5);          // Monitor totals
-  team_store(tile, i, L, E, (o.bits & AMENV_INFO_WAS_RESET) != 0);
-  team_store_outputs(L, o, uint32_t(i), active, obs, reward_out, done, info);
+  team_store(tile, i, L, E);
+  team_store_outputs<false>(L, o, uint32_t(i), active, obs, reward_out, done, info);
   AMENV_STAMP(6);          // stores issued
 #ifdef AMENV_STAMPS
   AMENV_STAMP_DRAIN();
@@ -503,18 +502,16 @@ __global__ __launch_bounds__(64) void rollout_kernel_team(void* __restrict__ blo
   const uint32_t ja = uint32_t(L.cc < 3 ? L.cc : 2);
   const float* ap = actions + size_t(ia) * AD;
   float act = ap[L.cc], actj = ap[4 + ja];
-  bool any_reset = false;
   for (int t = 0; t < n_steps; t++) {
     const float a_now = act, aj_now = actj;
     if (t + 1 < n_steps) { ap += n * AD; act = ap[L.cc]; actj = ap[4 + ja]; }   // next step's action: in flight during this step
     const TeamOut o = team_advance<NROT>(P, C, L, E, a_now, aj_now, i, active, nullptr, nullptr, nullptr);
-    any_reset |= (o.bits & AMENV_INFO_WAS_RESET) != 0;
     accumulate_stats(tl.stats, int(blockIdx.x), o.bits, active && o.ended && L.lead, o.ep_len, o.ep_ret);
     const size_t tn = size_t(t) * n;
-    team_store_outputs(L, o, uint32_t(i), active, obs ? obs + tn * OD : nullptr, reward_out ? reward_out + tn : nullptr, done ? done + tn : nullptr,
+    team_store_outputs<true>(L, o, uint32_t(i), active, obs ? obs + tn * OD : nullptr, reward_out ? reward_out + tn : nullptr, done ? done + tn : nullptr,
                        info ? info + tn : nullptr);
   }
-  team_store(tile, i, L, E, any_reset);
+  team_store(tile, i, L, E);
 }
 
 }  // namespace amenv_dev

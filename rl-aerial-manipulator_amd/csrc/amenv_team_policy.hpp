@@ -179,7 +179,6 @@ __global__ __launch_bounds__(256, OCC) void rollout_policy_kernel_team(void* __r
   };
   if (L.lead) { __bf16* xr = xin + el * kXS; xr[OD] = (__bf16)1.0f; xr[OD + 1] = (__bf16)0.0f; xr[OD + 2] = (__bf16)0.0f; }   // bias column, K padding
   publish_obs(io.obs + size_t(i) * OD);
-  bool any_reset = false;
   auto load_b = [&](const __bf16* base, int stride, int ks) {   // operand B: 8 consecutive inputs of env `nrow`
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + nrow * stride + 32 * ks + 8 * kq));
   };
@@ -265,7 +264,6 @@ __global__ __launch_bounds__(256, OCC) void rollout_policy_kernel_team(void* __r
     }
     // ---- env step
     const TeamOut o = team_advance<NROT>(P, C, L, E, act, actj, i, active, io.terminal_obs ? io.terminal_obs + tn * OD : nullptr, nullptr, nullptr);
-    any_reset |= (o.bits & AMENV_INFO_WAS_RESET) != 0;
     accumulate_stats(stats, int(blockIdx.x) * 4 + wave, o.bits, active && o.ended && L.lead, o.ep_len, o.ep_ret);
     if (active && L.lead) {
       io.rewards[tn + i] = o.reward;
@@ -275,7 +273,7 @@ __global__ __launch_bounds__(256, OCC) void rollout_policy_kernel_team(void* __r
     vA = o.vA; vB = o.vB; vC = o.vC;
     publish_obs(io.obs + (tn + n + i) * OD);                   // row t + 1, and the next step's MLP input (xin was last read before the second barrier)
   }
-  team_store(tile, i, L, E, any_reset);
+  team_store(tile, i, L, E);
 }
 
 }  // namespace amenv_dev
