@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--vehicle", default="quad")
+    ap.add_argument("--fused-rollout", action="store_true", help="collect_rollouts as one launch of amenv_rollout_policy (hexa_arm)")
     a = ap.parse_args()
     import torch
     import rl_aerial_manipulator_amd as amd
@@ -36,7 +37,7 @@ def main():
     sh = sharding.shard_from_env(a.envs)
     dist = sharding.init_process_group("nccl", dev)
     env = amd.GpuWaypointEnv(a.envs, device=local, vehicle=a.vehicle, seed=0, env_id_offset=sh.env_id_offset)
-    algo = amd.PPO(env, n_steps=a.n_steps, batch_size=a.batch, n_epochs=a.epochs, seed=0, dist=dist)
+    algo = amd.PPO(env, n_steps=a.n_steps, batch_size=a.batch, n_epochs=a.epochs, seed=0, dist=dist, fused_rollout=a.fused_rollout)
     t_roll = t_upd = 0.0
     rec = {}
     for it in range(a.warmup + a.iters):
