@@ -345,6 +345,18 @@ int amenv_ppo_loss_grad(const float* mean, const float* value, const float* log_
                         float vf_coef, int32_t normalize_advantage, float* d_mean, float* d_value, float* d_log_std, float* stats4,
                         void* workspace, void* stream);
 
+/* One whole PPO minibatch step of the reference's policy ([128, 64, 64] tanh actor + critic, v2/rl_train.py:27-30,38-53) in ONE fused
+ * kernel (+ a transpose of the weights in front and a fixed-order reduction behind): forward of both MLPs, SB3's loss as
+ * amenv_ppo_loss_grad computes it, backward through both MLPs, all weight / bias gradients.  fp32 in and out on the matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation), so the result differs from autograd on the fp32 torch modules by
+ * summation order only.  flat_params / flat_grad: the policy's parameters / their gradients in SB3 state-dict order (see
+ * amenv_policy_forward); obs [n, obs_dim], actions [n, act_dim], old_logp / advantages / returns [n] f32; stats4 as amenv_ppo_loss_grad.
+ * (obs_dim, act_dim) in {(20,4), (29,7), (17,4)}.  workspace: amenv_ppo_mlp_workspace_bytes() bytes, 16-byte aligned. */
+size_t amenv_ppo_mlp_workspace_bytes(void);
+int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, const float* actions, const float* old_logp,
+                       const float* advantages, const float* returns, int64_t n, float clip_range, float ent_coef, float vf_coef,
+                       int32_t normalize_advantage, float* flat_grad, float* stats4, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@
 #include "amenv_obsnorm.hpp"
 #include "amenv_policy.hpp"
 #include "amenv_train.hpp"
+#include "amenv_mlp_train.hpp"
 
 using namespace amenv_dev;
 
@@ -449,6 +450,27 @@ __global__ void calibration_copy_kernel(const V* __restrict__ src, V* __restrict
   for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) dst[i] = src[i];
 }
 
+}  // namespace
+
+// workspace of amenv_ppo_mlp_step: advantage partials | k-major weight copies of both nets | per-workgroup gradient slabs of both nets
+namespace {
+constexpr size_t kMlpWsAdv = size_t(2) * kPpoMaxBlocks * sizeof(double);
+constexpr size_t kMlpWsWt = size_t(2) * kMlpWtPerNet * sizeof(float);
+constexpr size_t kMlpWsPart = size_t(2) * kMlpMaxBlocks * kAccSize * sizeof(float);
+constexpr size_t kMlpLds = (size_t(kXposeRows) * kXs + 16) * sizeof(float);
+template <int D, int A>
+hipError_t launch_mlp_step(const float* Pm, const float* WT, const float* obs, const float* actions, const float* old_logp, const float* adv, const float* ret, int64_t n,
+                           float clip, float vf, int normalize, const double* adv_part, int adv_blocks, float* part, int blocks, hipStream_t s) {
+  static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_fused_kernel<D, A>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMlpLds));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ppo_mlp_fused_kernel<D, A>), dim3(blocks, 2), dim3(256), kMlpLds, s, Pm, WT, obs, actions, old_logp, adv, ret, n, clip, vf, normalize, adv_part,
+                     adv_blocks, part);
+  return hipGetLastError();
+}
 }  // namespace
 
 extern "C" {
@@ -932,6 +954,37 @@ int amenv_calibration_copy(const void* src, void* dst, size_t bytes, int32_t byt
   hipStream_t s = (hipStream_t)stream;
   if (bytes_per_lane == 4) hipLaunchKernelGGL((calibration_copy_kernel<float>), dim3(2048), dim3(256), 0, s, (const float*)src, (float*)dst, bytes / 4);
   else hipLaunchKernelGGL((calibration_copy_kernel<float4>), dim3(2048), dim3(256), 0, s, (const float4*)src, (float4*)dst, bytes / 16);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+size_t amenv_ppo_mlp_workspace_bytes(void) { return kMlpWsAdv + kMlpWsWt + kMlpWsPart; }
+
+int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, const float* actions, const float* old_logp,
+                       const float* advantages, const float* returns, int64_t n, float clip_range, float ent_coef, float vf_coef,
+                       int32_t normalize_advantage, float* flat_grad, float* stats4, void* workspace, void* stream) {
+  if (!flat_params || !obs || !actions || !old_logp || !advantages || !returns || !flat_grad || !stats4 || !workspace || n <= 0 || !(clip_range >= 0.0f) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15u))
+    return AMENV_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = static_cast<char*>(workspace);
+  double* adv_part = reinterpret_cast<double*>(ws);
+  float* WT = reinterpret_cast<float*>(ws + kMlpWsAdv);
+  float* part = reinterpret_cast<float*>(ws + kMlpWsAdv + kMlpWsWt);
+  const int adv_blocks = int(std::min<int64_t>(kPpoMaxBlocks, (n + kPpoBlock - 1) / kPpoBlock));
+  const int64_t ntiles = (n + 31) / 32;
+  const int blocks = int(std::min<int64_t>(128, (ntiles + 3) / 4));   // 128 x 2 nets x 4 wavefronts = one wavefront per SIMD
+  hipLaunchKernelGGL(ppo_adv_partials, dim3(adv_blocks), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part);
+  hipLaunchKernelGGL(mlp_transpose_kernel, dim3((2 * kMlpWtPerNet + 255) / 256), dim3(256), 0, s, flat_params, (int)obs_dim, (int)act_dim, WT);
+  hipError_t st;
+  if (obs_dim == 20 && act_dim == 4) st = launch_mlp_step<20, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  else if (obs_dim == 29 && act_dim == 7) st = launch_mlp_step<29, 7>(flat_params, WT, obs, actions, old_logp, advantages, returns, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  else if (obs_dim == 17 && act_dim == 4) st = launch_mlp_step<17, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  else return AMENV_ERR_INVALID;
+  if (st != hipSuccess) return AMENV_ERR_HIP;
+  const int trunk = kH1 * obs_dim + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;
+  const int total = act_dim + 2 * trunk + act_dim * kH3 + act_dim + kH3 + 1;
+  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((total + 4 + 255) / 256), dim3(256), 0, s, (const float*)part, blocks, (int)obs_dim, (int)act_dim, (int64_t)n, flat_params,
+                     ent_coef, flat_grad, stats4);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

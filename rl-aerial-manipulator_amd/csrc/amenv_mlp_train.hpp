@@ -1,0 +1,389 @@
+// amenv_mlp_train.hpp -- one PPO minibatch step of the reference's policy (v2/rl_train.py:38-56: SB3 MlpPolicy, net_arch [128, 64, 64],
+// tanh, separate actor / critic trunks) as ONE kernel: forward of both MLPs, SB3's loss and its gradient, backward through both MLPs and
+// all weight / bias gradients.  PyTorch ran this as ~90 library launches per minibatch (~0.9 ms for 65,536 samples, ~15 TFLOP/s).
+//
+// Arithmetic: fp32 in, fp32 out on the matrix cores -- v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fma chain, so the result
+// differs from torch's fp32 modules only by summation order (test: <= 2e-5 of the largest gradient entry).
+//
+// Data flow of one wavefront = one tile of 32 samples (blockIdx.y = net: 0 actor, 1 critic):
+//   * orientation D = W . X^T: M = 32 output neurons, N = the tile's 32 samples, K = inputs.  The accumulator tile of layer l (rows =
+//     neurons in the 16 registers, column = sample on the lane) IS the B operand of layer l + 1: k-step (tile t, register r) consumes,
+//     in lane half h, the neuron 32 t + (r & 3) + 8 (r >> 2) + 4 h -- exactly the row that register holds.  Activations never leave
+//     registers on the forward pass nor on the data-gradient pass (dH = W^T dZ has the same shape); tanh and tanh' are lane-local.
+//   * weights are the A operands, one coalesced 256-byte global load per MFMA (L2-resident: 66 KB per net): the forward reads the
+//     k-major copies W^T (made by mlp_transpose_kernel after every optimiser step), the data-gradient pass the row-major originals.
+//   * weight gradients contract over SAMPLES: the four wavefronts of a workgroup pool their tiles -- dZ and the layer inputs go through
+//     an LDS transpose ([neuron][128 samples + 1]: written lane = sample, read lane = neuron, both conflict-free) -- and every 32 x 32
+//     tile of every dW is OWNED by one wavefront, which accumulates it in registers over all samples the workgroup sees (64 k-steps per
+//     iteration).  No atomics: a first version added per-wavefront tiles into an LDS accumulator with ds_add_f32 and spent 76 % of its
+//     time there.  Bias gradients ride along as the running sum of the A fragments.  At the end a workgroup writes its tiles to a partial
+//     slab; mlp_grad_reduce_kernel sums the slabs in a fixed order into the flat gradient: the step is deterministic.
+//   * the loss part is SB3's (amenv_train.hpp ppo_loss_grad, same expressions), evaluated on the accumulator tile of the head: the 7
+//     action means of a sample sit in registers 0..3 of the two lane halves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "amenv_train.hpp"
+
+namespace amenv_dev {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kH1 = 128, kH2 = 64, kH3 = 64;
+// per net: W1^T [32][128] | W2^T [128][64] | W3^T [64][64] | W4^T [64][32] | W4 padded to 32 rows [32][64]  (zeros where a row / column does not exist)
+constexpr int kMlpWtPerNet = 32 * kH1 + kH1 * kH2 + kH2 * kH3 + kH3 * 32 + 32 * kH3;
+// per-workgroup gradient accumulator (floats): dW1 [128][33] (col 32 = bias) | dW2 [64][129] | dW3 [64][65] | dW4 [32][65] | stats [16]
+constexpr int kAccW1 = 0, kAccW2 = kAccW1 + kH1 * 33, kAccW3 = kAccW2 + kH2 * 129, kAccW4 = kAccW3 + kH3 * 65, kAccStats = kAccW4 + 32 * 65;
+constexpr int kAccSize = kAccStats + 16;
+constexpr int kXs = 129;                                                      // transpose row stride: 4 wavefronts x 32 samples + 1
+constexpr int kXposeRows = 192;                                               // largest layer: dZ2 (64 rows) + H1 (128 rows)
+constexpr int kMlpMaxBlocks = 256;
+
+__host__ __device__ constexpr int mlp_rowmap(int r) { return (r & 3) + 8 * (r >> 2); }   // row of accumulator register r (+ 4 for the upper lane half)
+
+__device__ __forceinline__ float tanh_acc(float x) {   // |err| ~1e-7: exp form, with the odd series where the exp form cancels
+  const float ax = __builtin_fabsf(x);
+  const float t = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+  const float x2 = x * x;
+  const float small = ax * fma_(x2, fma_(x2, 0.13333333333f, -0.33333333333f), 1.0f);
+  return __builtin_copysignf(ax < 0.06f ? small : big, x);
+}
+
+// trunk / head parameter offsets inside the flat buffer (SB3 order, see amenv_team_policy.hpp PolLayout)
+struct MlpNet {
+  const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;   // row-major originals
+  int n_out;                                             // head rows: A (actor) or 1 (critic)
+};
+__device__ __forceinline__ MlpNet mlp_net(const float* Pm, int D, int A, int net) {
+  const int trunk = kH1 * D + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;
+  const float* t = Pm + A + net * trunk;
+  MlpNet N;
+  N.W1 = t; N.b1 = t + kH1 * D; N.W2 = N.b1 + kH1; N.b2 = N.W2 + kH2 * kH1; N.W3 = N.b2 + kH2; N.b3 = N.W3 + kH3 * kH2;
+  const float* heads = Pm + A + 2 * trunk;
+  N.W4 = net == 0 ? heads : heads + A * kH3 + A; N.b4 = N.W4 + (net == 0 ? A : 1) * kH3;
+  N.n_out = net == 0 ? A : 1;
+  return N;
+}
+
+// k-major copies of the four weight matrices of both nets (forward-pass A operands): one thread per element
+__global__ void mlp_transpose_kernel(const float* __restrict__ Pm, int D, int A, float* __restrict__ WT) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= 2 * kMlpWtPerNet) return;
+  const int net = tid / kMlpWtPerNet, e = tid % kMlpWtPerNet;
+  const MlpNet N = mlp_net(Pm, D, A, net);
+  float v;
+  if (e < 32 * kH1) { const int k = e / kH1, n = e % kH1; v = k < D ? N.W1[n * D + k] : 0.0f; }
+  else if (e < 32 * kH1 + kH1 * kH2) { const int q = e - 32 * kH1, k = q / kH2, n = q % kH2; v = N.W2[n * kH1 + k]; }
+  else if (e < 32 * kH1 + kH1 * kH2 + kH2 * kH3) { const int q = e - 32 * kH1 - kH1 * kH2, k = q / kH3, n = q % kH3; v = N.W3[n * kH2 + k]; }
+  else if (e < 32 * kH1 + kH1 * kH2 + kH2 * kH3 + kH3 * 32) { const int q = e - 32 * kH1 - kH1 * kH2 - kH2 * kH3, k = q / 32, n = q % 32; v = n < N.n_out ? N.W4[n * kH3 + k] : 0.0f; }
+  else { const int q = e - 32 * kH1 - kH1 * kH2 - kH2 * kH3 - kH3 * 32, o = q / kH3, k = q % kH3; v = o < N.n_out ? N.W4[o * kH3 + k] : 0.0f; }
+  WT[tid] = v;
+}
+
+// out[tile] = sum_k Wk[k][32 tile + n] * in[k]  (+ bias), k = 32 t + rowmap(r) + 4 h over the KT input tiles.  Wk is k-major ([K][ld]),
+// zero-padded where a k or an output does not exist: the forward pass gives it W^T, the data-gradient pass the row-major W itself
+// (out index = input neuron).  Every A operand is ONE load "uniform base + per-lane 32-bit offset": `voff` = (4 h ld + n) * 4 bytes is
+// the only address register (passed through an empty asm by the caller once per sample tile, or hipcc hoists all ~600 loop-invariant
+// 64-bit addresses of the kernel out of the tile loop: 400 spilled registers).  Loads come in chunks of kMlpChunk k-steps, the next
+// chunk's issued before the current chunk's MFMAs, with a scheduling barrier per chunk.
+constexpr int kMlpChunk = 4;
+template <int KT, int NT, int RSTEPS, int LD>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ Wk, const float* __restrict__ bias, int n_valid, const f32x16* in, f32x16* out, uint32_t voff, int h) {
+  static_assert(RSTEPS % kMlpChunk == 0, "k-steps per input tile must be a multiple of the chunk");
+  constexpr int NCH = KT * RSTEPS / kMlpChunk, CPT = RSTEPS / kMlpChunk;   // chunks in all, chunks per input tile
+#pragma unroll
+  for (int tile = 0; tile < NT; tile++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = 32 * tile + mlp_rowmap(r) + 4 * h;
+      out[tile][r] = (bias && row < n_valid) ? bias[row] : 0.0f;
+    }
+  float a[2][kMlpChunk][NT];
+  auto load = [&](int c, int buf) {
+#pragma unroll
+    for (int j = 0; j < kMlpChunk; j++) {
+      const int k0 = 32 * (c / CPT) + mlp_rowmap((c % CPT) * kMlpChunk + j);     // + 4 h: in voff
+#pragma unroll
+      for (int tile = 0; tile < NT; tile++)
+        a[buf][j][tile] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Wk + k0 * LD + 32 * tile) + voff);
+    }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if (c + 1 < NCH) load(c + 1, (c + 1) & 1);
+#pragma unroll
+    for (int j = 0; j < kMlpChunk; j++) {
+      const float b = in[c / CPT][(c % CPT) * kMlpChunk + j];
+#pragma unroll
+      for (int tile = 0; tile < NT; tile++) out[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][j][tile], b, out[tile], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// accumulator tiles (lane = sample, registers = rows) -> LDS [row][kXs], this wavefront's 32 sample columns (lane = sample: conflict-free)
+template <int NTILES>
+__device__ __forceinline__ void xpose_store(float* buf, int row0, const f32x16* v, int col, int h) {
+#pragma unroll
+  for (int t = 0; t < NTILES; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) buf[(row0 + 32 * t + mlp_rowmap(r) + 4 * h) * kXs + col] = v[t][r];
+}
+
+// d[i] += sum over the workgroup's 128 samples of dZ[o-tile][s] H[i-tile][s] for NI input tiles (row = 32-row tile index in the LDS
+// transposes, lane n = neuron within the tile); bsum += this lane half's share of sum_s dZ[row n][s].
+template <int NI>
+__device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ, int zrow, const float* bufH, int hrow, int n, int h) {
+#pragma unroll 4
+  for (int t = 0; t < 64; t++) {
+    const float a = bufZ[(zrow + n) * kXs + 2 * t + h];
+    bsum += a;
+#pragma unroll
+    for (int i = 0; i < NI; i++) d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bufH[(hrow + 32 * i + n) * kXs + 2 * t + h], d[i], 0, 0, 0);
+  }
+}
+
+// write one owned 32 x 32 tile (rows = output neurons in registers, column = input neuron on the lane) and its bias column to the slab
+__device__ __forceinline__ void mlp_tile_out(float* slab, int stride, int row0, int col0, const f32x16& d, int n, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) slab[(row0 + mlp_rowmap(r) + 4 * h) * stride + col0 + n] = d[r];
+}
+
+struct MlpLoss { float clip, vf_coef, inv_n, mu, inv_sd; };
+
+#ifdef AMENV_MLP_STAMPS   // diagnostic build: clocks per phase (forward, loss, weight gradients, data gradients), summed into stats slots 11..14
+#define MLP_T0() unsigned long long t_ = __builtin_readcyclecounter()
+#define MLP_TK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_readcyclecounter(); tph[k] += float(n_ - t_); t_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MLP_T0()
+#define MLP_TK(k)
+#endif
+
+// One PPO minibatch: forward + loss + backward + weight gradients of both nets.  grid = (blocks, 2), 256 threads.
+template <int D, int A>
+__global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restrict__ Pm, const float* __restrict__ WT, const float* __restrict__ obs,
+                                                            const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
+                                                            const float* __restrict__ ret, int64_t n, float clip, float vf_coef, int normalize,
+                                                            const double* __restrict__ adv_part, int adv_blocks, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // transposes [kXposeRows][kXs] | stats [16]
+  float* xb = lds;
+  float* lstats = lds + kXposeRows * kXs;
+  const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63, nn = lane & 31, h = lane >> 5;
+  const int col = wave * 32 + nn;                          // this lane's sample column in the transposes
+  const int net = blockIdx.y;
+  if (threadIdx.x < 16) lstats[threadIdx.x] = 0.0f;
+  // advantage statistics: every block sums the partials in the same fixed order (as ppo_loss_grad)
+  MlpLoss Lp{clip, vf_coef, 1.0f / float(n), 0.0f, 1.0f};
+  if (normalize && n > 1) {
+    double S = 0.0, Q = 0.0;
+    for (int k = 0; k < adv_blocks; k++) { S += adv_part[2 * k]; Q += adv_part[2 * k + 1]; }
+    const double m = S / double(n);
+    const double var = fmax((Q - S * m) / double(n - 1), 0.0);
+    Lp.mu = float(m);
+    Lp.inv_sd = 1.0f / (float(sqrt(var)) + 1e-8f);
+  }
+  const MlpNet N = mlp_net(Pm, D, A, net);
+  const float* wt = WT + net * kMlpWtPerNet;
+  const float *W1T = wt, *W2T = wt + 32 * kH1, *W3T = W2T + kH1 * kH2, *W4T = W3T + kH2 * kH3, *W4P = W4T + kH3 * 32;
+  // per-lane byte offsets of the A-operand loads, one per leading dimension: (4 h ld + n) * 4
+  uint32_t vo128 = uint32_t(4 * h * 128 + nn) * 4u, vo64 = uint32_t(4 * h * 64 + nn) * 4u, vo32 = uint32_t(4 * h * 32 + nn) * 4u;
+  float els[4], isd[4];                                   // log_std / 1 / std of this lane's four head rows (actor)
+#pragma unroll
+  for (int r = 0; r < 4; r++) { const int k = r + 4 * h; els[r] = k < A ? Pm[k] : 0.0f; isd[r] = __expf(-els[r]); }
+  float s_dls[4] = {0, 0, 0, 0}, s_pol = 0.0f, s_val = 0.0f, s_clipn = 0.0f;
+#ifdef AMENV_MLP_STAMPS
+  float tph[4] = {0, 0, 0, 0};
+#endif
+  // weight-gradient tiles this wavefront owns, accumulated over every sample the workgroup sees:
+  //   dW1 [128 x 32]: o-tile = wave            dW2 [64 x 128]: o-tile = wave >> 1, i-tiles 2 (wave & 1) + {0, 1}
+  //   dW3 [64 x 64] : (wave >> 1, wave & 1)    dW4 [32 x 64] : i-tile = wave (wavefronts 0, 1)
+  f32x16 gW1[1], gW2[2], gW3[1], gW4[1];
+  float gb1 = 0.0f, gb2 = 0.0f, gb3 = 0.0f, gb4 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { gW1[0][r] = 0.0f; gW2[0][r] = 0.0f; gW2[1][r] = 0.0f; gW3[0][r] = 0.0f; gW4[0][r] = 0.0f; }
+  const int64_t ntiles = (n + 31) / 32;
+  const int64_t iters = (ntiles + int64_t(gridDim.x) * 4 - 1) / (int64_t(gridDim.x) * 4);   // the same for every wavefront: barriers inside
+  for (int64_t it = 0; it < iters; it++) {
+    const int64_t tile = (int64_t(blockIdx.x) * iters + it) * 4 + wave;
+    asm volatile("" : "+v"(vo128), "+v"(vo64), "+v"(vo32));   // keep the A-operand addresses inside the loop (see mlp_layer)
+    const int64_t s = tile * 32 + nn;
+    const bool sv = s < n;
+    const int64_t sc = sv ? s : n - 1;
+    // ---- forward
+    MLP_T0();
+    f32x16 X[1], H1[4], H2[2], H3[2], Y[1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const int k = mlp_rowmap(r) + 4 * h; X[0][r] = (sv && k < D) ? obs[sc * D + k] : 0.0f; }
+    mlp_layer<1, 4, 16, kH1>(W1T, N.b1, kH1, X, H1, vo128, h);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) H1[t][r] = tanh_acc(H1[t][r]);
+    mlp_layer<4, 2, 16, kH2>(W2T, N.b2, kH2, H1, H2, vo64, h);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) H2[t][r] = tanh_acc(H2[t][r]);
+    mlp_layer<2, 2, 16, kH3>(W3T, N.b3, kH3, H2, H3, vo64, h);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) H3[t][r] = tanh_acc(H3[t][r]);
+    mlp_layer<2, 1, 16, 32>(W4T, N.b4, N.n_out, H3, Y, vo32, h);
+    MLP_TK(0);
+    // ---- loss gradient with respect to the head outputs (rows 0..3 in lane half 0, 4..7 in half 1)
+    f32x16 dY[1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) dY[0][r] = 0.0f;
+    if (net == 0) {
+      float z[4], lp = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int k = r + 4 * h;
+        z[r] = k < A ? (actions[sc * A + k] - Y[0][r]) * isd[r] : 0.0f;
+        lp += k < A ? fma_(-0.5f * z[r], z[r], -els[r]) - 0.918938533204672742f : 0.0f;
+      }
+      lp += __shfl_xor(lp, 32);
+      const float ratio = __expf(lp - old_logp[sc]);
+      const float a = (adv[sc] - Lp.mu) * Lp.inv_sd;
+      const float s1 = a * ratio, s2 = a * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+      const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
+      const float g_lp = (sv && (inside || s1 < s2)) ? -a * ratio * Lp.inv_n : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        dY[0][r] = g_lp * z[r] * isd[r];
+        s_dls[r] += (r + 4 * h < A) ? g_lp * fma_(z[r], z[r], -1.0f) : 0.0f;
+      }
+      if (sv && h == 0) { s_pol += -fminf(s1, s2); s_clipn += fabsf(ratio - 1.0f) > clip ? 1.0f : 0.0f; }
+    } else if (h == 0) {
+      const float dv = ret[sc] - Y[0][0];
+      dY[0][0] = sv ? -2.0f * vf_coef * dv * Lp.inv_n : 0.0f;
+      if (sv) s_val += dv * dv;
+    }
+    MLP_TK(1);
+    // ---- backward.  Per layer: every wavefront publishes its samples' dZ and layer inputs, barrier, the owned dW tiles accumulate over the
+    // workgroup's 128 samples while the data gradient of the next layer (registers only) is formed, barrier before the area is rewritten.
+    float* xz = xb;                 // dZ rows
+    // head: dZ4 = dY (32 rows, 8 used), inputs H3 (64 rows)
+    __syncthreads();                // (previous iteration's readers are done)
+    xpose_store<1>(xz, 0, dY, col, h);
+    xpose_store<2>(xz, 32, H3, col, h);
+    __syncthreads();
+    if (wave < 2) mlp_dw<1>(gW4, gb4, xz, 0, xz, 32 + 32 * wave, nn, h);
+    MLP_TK(2);
+    f32x16 dZ3[2];
+    mlp_layer<1, 2, 4, kH3>(W4P, nullptr, 0, dY, dZ3, vo64, h);                   // dH3 = W4^T dY (rows 0..7 of dY only)
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dZ3[t][r] *= fma_(-H3[t][r], H3[t][r], 1.0f);
+    MLP_TK(3);
+    // layer 3: dZ3 (64 rows), inputs H2 (64 rows)
+    __syncthreads();
+    xpose_store<2>(xz, 0, dZ3, col, h);
+    xpose_store<2>(xz, 64, H2, col, h);
+    __syncthreads();
+    mlp_dw<1>(gW3, gb3, xz, 32 * (wave >> 1), xz, 64 + 32 * (wave & 1), nn, h);
+    MLP_TK(2);
+    f32x16 dZ2[2];
+    mlp_layer<2, 2, 16, kH2>(N.W3, nullptr, 0, dZ3, dZ2, vo64, h);                // dH2 = W3^T dZ3
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dZ2[t][r] *= fma_(-H2[t][r], H2[t][r], 1.0f);
+    MLP_TK(3);
+    // layer 2: dZ2 (64 rows), inputs H1 (128 rows)
+    __syncthreads();
+    xpose_store<2>(xz, 0, dZ2, col, h);
+    xpose_store<4>(xz, 64, H1, col, h);
+    __syncthreads();
+    mlp_dw<2>(gW2, gb2, xz, 32 * (wave >> 1), xz, 64 + 64 * (wave & 1), nn, h);
+    MLP_TK(2);
+    f32x16 dZ1[4];
+    mlp_layer<2, 4, 16, kH1>(N.W2, nullptr, 0, dZ2, dZ1, vo128, h);               // dH1 = W2^T dZ2
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dZ1[t][r] *= fma_(-H1[t][r], H1[t][r], 1.0f);
+    MLP_TK(3);
+    // layer 1: dZ1 (128 rows), inputs = the observation tile (32 rows)
+    __syncthreads();
+    xpose_store<4>(xz, 0, dZ1, col, h);
+    xpose_store<1>(xz, 128, X, col, h);
+    __syncthreads();
+    mlp_dw<1>(gW1, gb1, xz, 32 * wave, xz, 128, nn, h);
+    MLP_TK(2);
+  }
+  // ---- this workgroup's slab: owned tiles, bias columns (the two lane halves each summed half of the samples), loss sums
+  float* slab = part + (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * kAccSize;
+  mlp_tile_out(slab + kAccW1, 33, 32 * wave, 0, gW1[0], nn, h);
+  mlp_tile_out(slab + kAccW2, 129, 32 * (wave >> 1), 64 * (wave & 1), gW2[0], nn, h);
+  mlp_tile_out(slab + kAccW2, 129, 32 * (wave >> 1), 64 * (wave & 1) + 32, gW2[1], nn, h);
+  mlp_tile_out(slab + kAccW3, 65, 32 * (wave >> 1), 32 * (wave & 1), gW3[0], nn, h);
+  if (wave < 2) mlp_tile_out(slab + kAccW4, 65, 0, 32 * wave, gW4[0], nn, h);
+  gb1 += __shfl_xor(gb1, 32); gb2 += __shfl_xor(gb2, 32); gb3 += __shfl_xor(gb3, 32); gb4 += __shfl_xor(gb4, 32);
+  if (h == 0) {
+    slab[kAccW1 + (32 * wave + nn) * 33 + 32] = gb1;
+    if ((wave & 1) == 0) { slab[kAccW2 + (32 * (wave >> 1) + nn) * 129 + 128] = gb2; slab[kAccW3 + (32 * (wave >> 1) + nn) * 65 + 64] = gb3; }
+    if (wave == 0) slab[kAccW4 + nn * 65 + 64] = gb4;
+  }
+  // per-lane loss sums -> the stats slots (d log_std[0..A), policy, value, clip count); LDS adds, then one writer
+  if (net == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (r + 4 * h < A) atomicAdd(&lstats[r + 4 * h], s_dls[r]);
+    atomicAdd(&lstats[8], s_pol); atomicAdd(&lstats[10], s_clipn);
+  } else atomicAdd(&lstats[9], s_val);
+#ifdef AMENV_MLP_STAMPS
+  if (lane == 0) for (int k = 0; k < 4; k++) atomicAdd(&lstats[11 + k], tph[k]);
+#endif
+  __syncthreads();
+  if (threadIdx.x < 16) slab[kAccStats + threadIdx.x] = lstats[threadIdx.x];
+}
+
+// Fixed-order sum of the per-workgroup slabs into the flat gradient (SB3 parameter order) + d log_std + the four reported scalars.
+// One thread per parameter (+ 4 for the stats).
+__global__ void mlp_grad_reduce_kernel(const float* __restrict__ part, int blocks, int D, int A, int64_t n, const float* __restrict__ Pm, float ent_coef,
+                                       float* __restrict__ grad, float* __restrict__ stats) {
+  const int trunk = kH1 * D + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;
+  const int total = A + 2 * trunk + A * kH3 + A + kH3 + 1;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total + 4) return;
+  auto sum = [&](int net, int slot) {
+    float t = 0.0f;
+    const float* p = part + size_t(net) * blocks * kAccSize + slot;
+    for (int b = 0; b < blocks; b++) t += p[size_t(b) * kAccSize];
+    return t;
+  };
+  if (tid >= total) {   // stats: policy loss, value loss, entropy loss, clip fraction
+    const int k = tid - total;
+    if (k == 0) stats[0] = sum(0, kAccStats + 8) / float(n);
+    else if (k == 1) stats[1] = sum(1, kAccStats + 9) / float(n);
+    else if (k == 2) { float e = 0.0f; for (int j = 0; j < A; j++) e += 1.418938533204672742f + Pm[j]; stats[2] = -e; }
+    else stats[3] = sum(0, kAccStats + 10) / float(n);
+    return;
+  }
+  if (tid < A) { grad[tid] = sum(0, kAccStats + tid) - ent_coef; return; }
+  int e = tid - A, net, slot;
+  if (e < 2 * trunk) {
+    net = e / trunk; e %= trunk;
+    if (e < kH1 * D) slot = kAccW1 + (e / D) * 33 + e % D;
+    else if ((e -= kH1 * D) < kH1) slot = kAccW1 + e * 33 + 32;
+    else if ((e -= kH1) < kH2 * kH1) slot = kAccW2 + (e / kH1) * 129 + e % kH1;
+    else if ((e -= kH2 * kH1) < kH2) slot = kAccW2 + e * 129 + 128;
+    else if ((e -= kH2) < kH3 * kH2) slot = kAccW3 + (e / kH2) * 65 + e % kH2;
+    else { e -= kH3 * kH2; slot = kAccW3 + e * 65 + 64; }
+  } else {
+    e -= 2 * trunk;
+    if (e < A * kH3) { net = 0; slot = kAccW4 + (e / kH3) * 65 + e % kH3; }
+    else if ((e -= A * kH3) < A) { net = 0; slot = kAccW4 + e * 65 + 64; }
+    else if ((e -= A) < kH3) { net = 1; slot = kAccW4 + e; }
+    else { net = 1; slot = kAccW4 + 64; }
+  }
+  grad[tid] = sum(net, slot);
+}
+
+}  // namespace amenv_dev

@@ -275,7 +275,7 @@ class MinibatchStep:
     all-reduce of the flat gradient buffer.  A ragged last minibatch (n % batch_size) always runs eagerly."""
 
     def __init__(self, policy, optimizer, *, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5,
-                 normalize_advantage=True, dist=None, use_graph=None, split_graphs=None, fused_loss=None):
+                 normalize_advantage=True, dist=None, use_graph=None, split_graphs=None, fused_loss=None, fused_mlp=None):
         if policy.flat_grad is None:
             policy.flatten_()
         self.policy, self.optimizer, self.dist = policy, optimizer, dist
@@ -294,12 +294,19 @@ class MinibatchStep:
         # loss + its gradient in the HIP kernels (amenv_ppo_loss_grad) on the GPU; the torch expression is the host-side statement
         self.fused_loss = (dev.type == "cuda") if fused_loss is None else bool(fused_loss)
         self._fused_buf = None
+        # the whole forward / loss / backward of both MLPs in ONE kernel on the fp32 matrix cores (amenv_ppo_mlp_step) where the policy
+        # has the reference's architecture; the torch modules + fused loss otherwise
+        ok = dev.type == "cuda" and getattr(policy, "net_arch", None) == (128, 64, 64) and (policy.obs_dim, policy.act_dim) in policy._FUSED_DIMS
+        self.fused_mlp = ok if fused_mlp is None else (bool(fused_mlp) and ok)
+        self._mlp_ws = None
         self._static = None
         self._graphs = None
         self._eager_calls = 0
 
     # -- the arithmetic (shared by the eager and the captured path) --------------------------------
     def _forward_backward(self, obs, actions, old_logp, adv, ret):
+        if self.fused_mlp:
+            return self._forward_backward_mlp(obs, actions, old_logp, adv, ret)
         if self.fused_loss:
             return self._forward_backward_fused(obs, actions, old_logp, adv, ret)
         if self.normalize_advantage and adv.numel() > 1:
@@ -338,6 +345,20 @@ class MinibatchStep:
             raise L.AmenvError(f"amenv_ppo_loss_grad failed ({rc})")
         grads = torch.autograd.grad([mean, values], self._net_params, grad_outputs=[d_mean, d_value])
         torch.cat([d_log_std] + [g.reshape(-1) for g in grads], out=pol.flat_grad)     # log_std is the first parameter
+
+    def _forward_backward_mlp(self, obs, actions, old_logp, adv, ret):
+        """Forward, SB3's loss, backward and every weight gradient in ONE kernel (csrc/amenv_mlp_train.hpp): the gradient lands in the flat
+        buffer, the four reported scalars in `stats`.  fp32 throughout (v_mfma_f32_32x32x2_f32), autograd is not involved."""
+        pol = self.policy
+        if self._mlp_ws is None:
+            self._mlp_ws = torch.empty(L.load().amenv_ppo_mlp_workspace_bytes() // 8 + 2, dtype=torch.float64, device=obs.device)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        obs, actions = obs.contiguous(), actions.contiguous()
+        rc = L.load().amenv_ppo_mlp_step(p(pol.flat_param.detach()), pol.obs_dim, pol.act_dim, p(obs), p(actions), p(old_logp), p(adv), p(ret), obs.shape[0],
+                                         self.clip_range, self.ent_coef, self.vf_coef, 1 if self.normalize_advantage else 0, p(pol.flat_grad), p(self.stats),
+                                         p(self._mlp_ws), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        if rc != 0:
+            raise L.AmenvError(f"amenv_ppo_mlp_step failed ({rc})")
 
     def _exchange(self):
         if self.dist is not None and (self.world > 1 or self.split):

@@ -446,3 +446,47 @@ def test_fused_rollout_feeds_the_update():
     assert algo.num_timesteps == 3 * N and float((algo.policy.flat_param.detach() - p0).abs().max()) > 1e-5
     assert all(math.isfinite(x) for rec in algo.log for x in rec.values())
     env.close()
+
+
+@pytest.mark.parametrize("D,A,n", [(29, 7, 8192), (20, 4, 5000), (17, 4, 31), (29, 7, 65536)])
+def test_fused_mlp_step_matches_autograd(D, A, n):
+    """amenv_ppo_mlp_step (forward + SB3 loss + backward + all weight gradients of both MLPs in one kernel, fp32 on the matrix cores)
+    against autograd on the fp32 torch modules with the torch statement of the loss: every gradient entry within 2e-5 of the largest,
+    the four reported scalars equal; ragged batch sizes (n not a multiple of 32) included."""
+    from rl_aerial_manipulator_amd.ppo import MinibatchStep
+    torch.manual_seed(3)
+    pol = ActorCritic(D, A).cuda().flatten_()
+    with torch.no_grad():
+        pol.log_std.data.copy_(torch.linspace(-0.7, 0.2, A))
+        pol.action_net.weight.mul_(20.0)
+    opt = torch.optim.Adam([pol.flat_param.requires_grad_(True)], lr=1e-3)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = torch.randn(n, D, device="cuda", generator=g) * 0.7
+    with torch.no_grad():
+        mean = pol.action_net(pol.mlp_extractor.policy_net(obs))
+    actions = mean + torch.exp(pol.log_std.detach()) * torch.randn(n, A, device="cuda", generator=g)
+    with torch.no_grad():
+        _, logp, _ = pol.evaluate_actions(obs, actions)
+    old_logp = logp + 0.15 * torch.randn(n, device="cuda", generator=g)      # ratios spread around 1: both sides of the clip fire
+    adv = torch.randn(n, device="cuda", generator=g) * 3.0 + 0.5
+    ret = torch.randn(n, device="cuda", generator=g) * 2.0
+    outs = []
+    for fused in (False, True):
+        step = MinibatchStep(pol, opt, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, use_graph=False, fused_loss=False, fused_mlp=fused)
+        assert step.fused_mlp == fused
+        pol.flat_grad.zero_()
+        step._forward_backward(obs, actions, old_logp, adv, ret)
+        torch.cuda.synchronize()
+        outs.append((pol.flat_grad.clone(), step.stats[:4].clone()))
+    (g0, s0), (g1, s1) = outs
+    scale = float(g0.abs().max())
+    assert scale > 0 and float((g0 - g1).abs().max()) < 2e-5 * scale, (float((g0 - g1).abs().max()), scale)
+    # per parameter block as well: small blocks (biases, log_std) are not hidden behind the largest entry
+    off = 0
+    for p_ in pol.parameters():
+        k = p_.numel()
+        blk = float(g0[off:off + k].abs().max())
+        assert float((g0[off:off + k] - g1[off:off + k]).abs().max()) < 1e-4 * max(blk, 1e-3 * scale), (off, k)
+        off += k
+    assert torch.allclose(s0, s1, rtol=2e-4, atol=1e-6), (s0, s1)
+    assert 0.02 < float(s1[3]) < 0.9                                       # clip fraction: the clipped branch was exercised
