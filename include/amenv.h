@@ -351,11 +351,23 @@ int amenv_ppo_loss_grad(const float* mean, const float* value, const float* log_
  * (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation), so the result differs from autograd on the fp32 torch modules by
  * summation order only.  flat_params / flat_grad: the policy's parameters / their gradients in SB3 state-dict order (see
  * amenv_policy_forward); obs [n, obs_dim], actions [n, act_dim], old_logp / advantages / returns [n] f32; stats4 as amenv_ppo_loss_grad.
- * (obs_dim, act_dim) in {(20,4), (29,7), (17,4)}.  workspace: amenv_ppo_mlp_workspace_bytes() bytes, 16-byte aligned. */
+ * (obs_dim, act_dim) in {(20,4), (29,7), (17,4)}.  index: NULL, or n row numbers -- minibatch sample s is row index[s] of obs / actions /
+ * old_logp / advantages / returns (SB3 draws its minibatches as slices of a permutation of the rollout buffer, RolloutBuffer.get: the
+ * gather happens inside the kernel, the rollout tensors stay where they are).  Deterministic: no atomics on the gradient path.
+ * workspace: amenv_ppo_mlp_workspace_bytes() bytes, 16-byte aligned. */
 size_t amenv_ppo_mlp_workspace_bytes(void);
 int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, const float* actions, const float* old_logp,
-                       const float* advantages, const float* returns, int64_t n, float clip_range, float ent_coef, float vf_coef,
-                       int32_t normalize_advantage, float* flat_grad, float* stats4, void* workspace, void* stream);
+                       const float* advantages, const float* returns, const int64_t* index, int64_t n, float clip_range, float ent_coef,
+                       float vf_coef, int32_t normalize_advantage, float* flat_grad, float* stats4, void* workspace, void* stream);
+
+/* Gradient-norm clip + Adam on the flat parameter buffer, one launch (the torch.nn.utils.clip_grad_norm_ + torch.optim.Adam step of SB3's
+ * PPO.train(); Adam with eps 1e-5, v2/rl_train.py:38 through SB3's defaults).  exp_avg / exp_avg_sq / step: torch.optim.Adam's state for
+ * that parameter (step: ONE f32 on the device, as torch keeps it with capturable=True; incremented here).  hyper6 (device): lr, beta1,
+ * beta2, eps, max_grad_norm (<= 0: no clipping), grad_scale (multiplies the gradient first: 1 / world size after a sum all-reduce).
+ * flat_grad is left scaled and clipped, grad_norm_out (may be NULL) receives the norm before clipping.  ticket: one zero-initialised
+ * device word the kernel uses and leaves zero. */
+int amenv_ppo_adam_step(float* flat_params, float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6,
+                        float* grad_norm_out, uint32_t* ticket, void* stream);
 
 #ifdef __cplusplus
 }

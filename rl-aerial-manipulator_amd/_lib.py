@@ -96,7 +96,8 @@ SYMBOLS = {
     "amenv_ppo_workspace_bytes": (C.c_size_t, []),
     "amenv_ppo_loss_grad": (C.c_int, [_P] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "amenv_ppo_mlp_workspace_bytes": (C.c_size_t, []),
-    "amenv_ppo_mlp_step": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 5 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, _P, _P, _P, _P]),
+    "amenv_ppo_mlp_step": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 6 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, _P, _P, _P, _P]),
+    "amenv_ppo_adam_step": (C.c_int, [_P] * 5 + [C.c_int64, _P, _P, _P, _P]),
     "amenv_gaussian_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_int64, _P]),
 }
 

@@ -457,9 +457,10 @@ namespace {
 constexpr size_t kMlpWsAdv = size_t(2) * kPpoMaxBlocks * sizeof(double);
 constexpr size_t kMlpWsWt = size_t(2) * kMlpWtPerNet * sizeof(float);
 constexpr size_t kMlpWsPart = size_t(2) * kMlpMaxBlocks * kAccSize * sizeof(float);
-constexpr size_t kMlpLds = (size_t(kXposeRows) * kXs + 16) * sizeof(float);
+constexpr size_t kMlpLds = (size_t(kXposeRows) * kXs + 64) * sizeof(float);
 template <int D, int A>
-hipError_t launch_mlp_step(const float* Pm, const float* WT, const float* obs, const float* actions, const float* old_logp, const float* adv, const float* ret, int64_t n,
+hipError_t launch_mlp_step(const float* Pm, const float* WT, const float* obs, const float* actions, const float* old_logp, const float* adv, const float* ret,
+                           const int64_t* index, int64_t n,
                            float clip, float vf, int normalize, const double* adv_part, int adv_blocks, float* part, int blocks, hipStream_t s) {
   static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per kernel
   if (!attr_set) {
@@ -467,7 +468,7 @@ hipError_t launch_mlp_step(const float* Pm, const float* WT, const float* obs, c
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_mlp_fused_kernel<D, A>), dim3(blocks, 2), dim3(256), kMlpLds, s, Pm, WT, obs, actions, old_logp, adv, ret, n, clip, vf, normalize, adv_part,
+  hipLaunchKernelGGL((ppo_mlp_fused_kernel<D, A>), dim3(blocks, 2), dim3(256), kMlpLds, s, Pm, WT, obs, actions, old_logp, adv, ret, index, n, clip, vf, normalize, adv_part,
                      adv_blocks, part);
   return hipGetLastError();
 }
@@ -960,7 +961,7 @@ int amenv_calibration_copy(const void* src, void* dst, size_t bytes, int32_t byt
 size_t amenv_ppo_mlp_workspace_bytes(void) { return kMlpWsAdv + kMlpWsWt + kMlpWsPart; }
 
 int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, const float* actions, const float* old_logp,
-                       const float* advantages, const float* returns, int64_t n, float clip_range, float ent_coef, float vf_coef,
+                       const float* advantages, const float* returns, const int64_t* index, int64_t n, float clip_range, float ent_coef, float vf_coef,
                        int32_t normalize_advantage, float* flat_grad, float* stats4, void* workspace, void* stream) {
   if (!flat_params || !obs || !actions || !old_logp || !advantages || !returns || !flat_grad || !stats4 || !workspace || n <= 0 || !(clip_range >= 0.0f) ||
       (reinterpret_cast<uintptr_t>(workspace) & 15u))
@@ -973,18 +974,27 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
   const int adv_blocks = int(std::min<int64_t>(kPpoMaxBlocks, (n + kPpoBlock - 1) / kPpoBlock));
   const int64_t ntiles = (n + 31) / 32;
   const int blocks = int(std::min<int64_t>(128, (ntiles + 3) / 4));   // 128 x 2 nets x 4 wavefronts = one wavefront per SIMD
-  hipLaunchKernelGGL(ppo_adv_partials, dim3(adv_blocks), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part);
+  hipLaunchKernelGGL(ppo_adv_partials, dim3(adv_blocks), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part, index);
   hipLaunchKernelGGL(mlp_transpose_kernel, dim3((2 * kMlpWtPerNet + 255) / 256), dim3(256), 0, s, flat_params, (int)obs_dim, (int)act_dim, WT);
   hipError_t st;
-  if (obs_dim == 20 && act_dim == 4) st = launch_mlp_step<20, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
-  else if (obs_dim == 29 && act_dim == 7) st = launch_mlp_step<29, 7>(flat_params, WT, obs, actions, old_logp, advantages, returns, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
-  else if (obs_dim == 17 && act_dim == 4) st = launch_mlp_step<17, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  if (obs_dim == 20 && act_dim == 4) st = launch_mlp_step<20, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  else if (obs_dim == 29 && act_dim == 7) st = launch_mlp_step<29, 7>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  else if (obs_dim == 17 && act_dim == 4) st = launch_mlp_step<17, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
   else return AMENV_ERR_INVALID;
   if (st != hipSuccess) return AMENV_ERR_HIP;
   const int trunk = kH1 * obs_dim + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;
   const int total = act_dim + 2 * trunk + act_dim * kH3 + act_dim + kH3 + 1;
-  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((total + 4 + 255) / 256), dim3(256), 0, s, (const float*)part, blocks, (int)obs_dim, (int)act_dim, (int64_t)n, flat_params,
+  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((total + 4 + 63) / 64), dim3(256), 0, s, (const float*)part, blocks, (int)obs_dim, (int)act_dim, (int64_t)n, flat_params,
                      ent_coef, flat_grad, stats4);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+int amenv_ppo_adam_step(float* flat_params, float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6, float* grad_norm_out,
+                        uint32_t* ticket, void* stream) {
+  if (!flat_params || !flat_grad || !exp_avg || !exp_avg_sq || !step || !hyper6 || !ticket || n <= 0) return AMENV_ERR_INVALID;
+  const int blocks = int(std::min<int64_t>(kAdamMaxBlocks, (n + kAdamBlock - 1) / kAdamBlock));
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(kAdamBlock), 0, (hipStream_t)stream, flat_params, flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6,
+                     grad_norm_out, ticket);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

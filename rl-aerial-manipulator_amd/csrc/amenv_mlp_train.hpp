@@ -86,13 +86,17 @@ __global__ void mlp_transpose_kernel(const float* __restrict__ Pm, int D, int A,
 // zero-padded where a k or an output does not exist: the forward pass gives it W^T, the data-gradient pass the row-major W itself
 // (out index = input neuron).  Every A operand is ONE load "uniform base + per-lane 32-bit offset": `voff` = (4 h ld + n) * 4 bytes is
 // the only address register (passed through an empty asm by the caller once per sample tile, or hipcc hoists all ~600 loop-invariant
-// 64-bit addresses of the kernel out of the tile loop: 400 spilled registers).  Loads come in chunks of kMlpChunk k-steps, the next
-// chunk's issued before the current chunk's MFMAs, with a scheduling barrier per chunk.
-constexpr int kMlpChunk = 4;
-template <int KT, int NT, int RSTEPS, int LD>
-__device__ __forceinline__ void mlp_layer(const float* __restrict__ Wk, const float* __restrict__ bias, int n_valid, const f32x16* in, f32x16* out, uint32_t voff, int h) {
-  static_assert(RSTEPS % kMlpChunk == 0, "k-steps per input tile must be a multiple of the chunk");
-  constexpr int NCH = KT * RSTEPS / kMlpChunk, CPT = RSTEPS / kMlpChunk;   // chunks in all, chunks per input tile
+// 64-bit addresses of the kernel out of the tile loop: 400 spilled registers).
+// Order: OUTPUT-tile major, one chunk = the k-steps of one input tile (16 MFMAs, 1024 clocks of matrix-core time -- above the L2 latency
+// of the next chunk's loads, which are issued first).  A finished tile's epilogue (tanh, or the tanh derivative of the backward pass) is
+// spread, element by element, between the MFMAs of the NEXT tile: the vector ALU works in the shadow of the matrix pipe instead of after
+// it (a k-major version with the activations as separate loops spent half of the forward pass outside the MFMAs).
+enum { kEpiNone = 0, kEpiTanh = 1, kEpiDtanh = 2 };
+template <int KT, int NT, int RSTEPS, int LD, int EPI>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ Wk, const float* __restrict__ bias, int n_valid, const f32x16* in, f32x16* out, uint32_t voff, int h,
+                                          const f32x16* act = nullptr) {
+  constexpr int CH = RSTEPS, NCH = NT * KT, SLOTS = KT * CH;      // chunk stream: (output tile, input tile); MFMA slots per output tile
+  constexpr int EPS = (16 + SLOTS - 1) / SLOTS;                    // epilogue elements placed after each MFMA (1 when SLOTS >= 16)
 #pragma unroll
   for (int tile = 0; tile < NT; tile++)
 #pragma unroll
@@ -100,27 +104,39 @@ __device__ __forceinline__ void mlp_layer(const float* __restrict__ Wk, const fl
       const int row = 32 * tile + mlp_rowmap(r) + 4 * h;
       out[tile][r] = (bias && row < n_valid) ? bias[row] : 0.0f;
     }
-  float a[2][kMlpChunk][NT];
+  auto epi = [&](int tile, int r) {
+    if (EPI == kEpiTanh) out[tile][r] = tanh_acc(out[tile][r]);
+    else if (EPI == kEpiDtanh) out[tile][r] *= fma_(-act[tile][r], act[tile][r], 1.0f);
+  };
+  float a[2][CH];
   auto load = [&](int c, int buf) {
 #pragma unroll
-    for (int j = 0; j < kMlpChunk; j++) {
-      const int k0 = 32 * (c / CPT) + mlp_rowmap((c % CPT) * kMlpChunk + j);     // + 4 h: in voff
-#pragma unroll
-      for (int tile = 0; tile < NT; tile++)
-        a[buf][j][tile] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Wk + k0 * LD + 32 * tile) + voff);
-    }
+    for (int j = 0; j < CH; j++)
+      a[buf][j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Wk + (32 * (c % KT) + mlp_rowmap(j)) * LD + 32 * (c / KT)) + voff);   // + 4 h: in voff
   };
   load(0, 0);
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     if (c + 1 < NCH) load(c + 1, (c + 1) & 1);
+    const int tile = c / KT, kt = c % KT;
 #pragma unroll
-    for (int j = 0; j < kMlpChunk; j++) {
-      const float b = in[c / CPT][(c % CPT) * kMlpChunk + j];
+    for (int j = 0; j < CH; j++) {
+      out[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][j], in[kt][j], out[tile], 0, 0, 0);
+      if (EPI != kEpiNone && tile > 0) {
+        const int slot = kt * CH + j;
+        if (SLOTS >= 16) { if (slot % (SLOTS / 16) == 0) epi(tile - 1, slot / (SLOTS / 16)); }
+        else {
 #pragma unroll
-      for (int tile = 0; tile < NT; tile++) out[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][j][tile], b, out[tile], 0, 0, 0);
+          for (int e = 0; e < EPS; e++) if (slot * EPS + e < 16) epi(tile - 1, slot * EPS + e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if (EPI != kEpiNone) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) epi(NT - 1, r);
   }
 }
 
@@ -137,12 +153,50 @@ __device__ __forceinline__ void xpose_store(float* buf, int row0, const f32x16* 
 // transposes, lane n = neuron within the tile); bsum += this lane half's share of sum_s dZ[row n][s].
 template <int NI>
 __device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ, int zrow, const float* bufH, int hrow, int n, int h) {
+#ifndef MLP_DW_CHUNK
+#define MLP_DW_CHUNK 8
+#endif
+#ifdef MLP_DW_OLD
 #pragma unroll 4
   for (int t = 0; t < 64; t++) {
     const float a = bufZ[(zrow + n) * kXs + 2 * t + h];
     bsum += a;
 #pragma unroll
     for (int i = 0; i < NI; i++) d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bufH[(hrow + 32 * i + n) * kXs + 2 * t + h], d[i], 0, 0, 0);
+  }
+  return;
+#endif
+  constexpr int CH = MLP_DW_CHUNK / NI, NCH = 64 / CH;                 // LDS reads one chunk ahead of the MFMAs that use them
+  const float* pz = bufZ + (zrow + n) * kXs + h;
+  const float* ph = bufH + (hrow + n) * kXs + h;
+  float a[2][CH], b[2][CH][NI];
+  auto load = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+      a[buf][j] = pz[2 * j];
+#pragma unroll
+      for (int i = 0; i < NI; i++) b[buf][j][i] = ph[32 * i * kXs + 2 * j];
+    }
+    pz += 2 * CH; ph += 2 * CH;
+  };
+  auto mac = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+      bsum += a[buf][j];
+#pragma unroll
+      for (int i = 0; i < NI; i++) d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][j], b[buf][j][i], d[i], 0, 0, 0);
+    }
+  };
+  load(0);
+#pragma unroll 1
+  for (int c = 0; c < NCH; c += 2) {           // a rolled loop (two chunks per trip): unrolled, the register allocator spills
+    load(1);
+    mac(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 == NCH) { pz -= 2 * CH; ph -= 2 * CH; }   // last trip: re-read the last chunk instead of running past the row
+    load(0);
+    mac(1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -166,15 +220,16 @@ struct MlpLoss { float clip, vf_coef, inv_n, mu, inv_sd; };
 template <int D, int A>
 __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restrict__ Pm, const float* __restrict__ WT, const float* __restrict__ obs,
                                                             const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
-                                                            const float* __restrict__ ret, int64_t n, float clip, float vf_coef, int normalize,
-                                                            const double* __restrict__ adv_part, int adv_blocks, float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // transposes [kXposeRows][kXs] | stats [16]
+                                                            const float* __restrict__ ret, const int64_t* __restrict__ index, int64_t n, float clip,
+                                                            float vf_coef, int normalize, const double* __restrict__ adv_part, int adv_blocks,
+                                                            float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // transposes [kXposeRows][kXs] | stats [4 wavefronts][16]
   float* xb = lds;
   float* lstats = lds + kXposeRows * kXs;
   const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63, nn = lane & 31, h = lane >> 5;
   const int col = wave * 32 + nn;                          // this lane's sample column in the transposes
   const int net = blockIdx.y;
-  if (threadIdx.x < 16) lstats[threadIdx.x] = 0.0f;
+  if (threadIdx.x < 64) lstats[threadIdx.x] = 0.0f;
   // advantage statistics: every block sums the partials in the same fixed order (as ppo_loss_grad)
   MlpLoss Lp{clip, vf_coef, 1.0f / float(n), 0.0f, 1.0f};
   if (normalize && n > 1) {
@@ -211,28 +266,21 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     asm volatile("" : "+v"(vo128), "+v"(vo64), "+v"(vo32));   // keep the A-operand addresses inside the loop (see mlp_layer)
     const int64_t s = tile * 32 + nn;
     const bool sv = s < n;
-    const int64_t sc = sv ? s : n - 1;
+    const int64_t sl = sv ? s : n - 1;
+#ifdef MLP_NO_INDEX
+    const int64_t sc = sl;
+#else
+    const int64_t sc = index ? index[sl] : sl;            // row of this sample in the rollout tensors
+#endif
     // ---- forward
     MLP_T0();
     f32x16 X[1], H1[4], H2[2], H3[2], Y[1];
 #pragma unroll
     for (int r = 0; r < 16; r++) { const int k = mlp_rowmap(r) + 4 * h; X[0][r] = (sv && k < D) ? obs[sc * D + k] : 0.0f; }
-    mlp_layer<1, 4, 16, kH1>(W1T, N.b1, kH1, X, H1, vo128, h);
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) H1[t][r] = tanh_acc(H1[t][r]);
-    mlp_layer<4, 2, 16, kH2>(W2T, N.b2, kH2, H1, H2, vo64, h);
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) H2[t][r] = tanh_acc(H2[t][r]);
-    mlp_layer<2, 2, 16, kH3>(W3T, N.b3, kH3, H2, H3, vo64, h);
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) H3[t][r] = tanh_acc(H3[t][r]);
-    mlp_layer<2, 1, 16, 32>(W4T, N.b4, N.n_out, H3, Y, vo32, h);
+    mlp_layer<1, 4, 16, kH1, kEpiTanh>(W1T, N.b1, kH1, X, H1, vo128, h);
+    mlp_layer<4, 2, 16, kH2, kEpiTanh>(W2T, N.b2, kH2, H1, H2, vo64, h);
+    mlp_layer<2, 2, 16, kH3, kEpiTanh>(W3T, N.b3, kH3, H2, H3, vo64, h);
+    mlp_layer<2, 1, 16, 32, kEpiNone>(W4T, N.b4, N.n_out, H3, Y, vo32, h);
     MLP_TK(0);
     // ---- loss gradient with respect to the head outputs (rows 0..3 in lane half 0, 4..7 in half 1)
     f32x16 dY[1];
@@ -275,11 +323,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     if (wave < 2) mlp_dw<1>(gW4, gb4, xz, 0, xz, 32 + 32 * wave, nn, h);
     MLP_TK(2);
     f32x16 dZ3[2];
-    mlp_layer<1, 2, 4, kH3>(W4P, nullptr, 0, dY, dZ3, vo64, h);                   // dH3 = W4^T dY (rows 0..7 of dY only)
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) dZ3[t][r] *= fma_(-H3[t][r], H3[t][r], 1.0f);
+    mlp_layer<1, 2, 4, kH3, kEpiDtanh>(W4P, nullptr, 0, dY, dZ3, vo64, h, H3);     // dZ3 = (W4^T dY) (1 - H3^2)  (rows 0..7 of dY only)
     MLP_TK(3);
     // layer 3: dZ3 (64 rows), inputs H2 (64 rows)
     __syncthreads();
@@ -289,11 +333,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     mlp_dw<1>(gW3, gb3, xz, 32 * (wave >> 1), xz, 64 + 32 * (wave & 1), nn, h);
     MLP_TK(2);
     f32x16 dZ2[2];
-    mlp_layer<2, 2, 16, kH2>(N.W3, nullptr, 0, dZ3, dZ2, vo64, h);                // dH2 = W3^T dZ3
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) dZ2[t][r] *= fma_(-H2[t][r], H2[t][r], 1.0f);
+    mlp_layer<2, 2, 16, kH2, kEpiDtanh>(N.W3, nullptr, 0, dZ3, dZ2, vo64, h, H2);  // dZ2 = (W3^T dZ3) (1 - H2^2)
     MLP_TK(3);
     // layer 2: dZ2 (64 rows), inputs H1 (128 rows)
     __syncthreads();
@@ -303,11 +343,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     mlp_dw<2>(gW2, gb2, xz, 32 * (wave >> 1), xz, 64 + 64 * (wave & 1), nn, h);
     MLP_TK(2);
     f32x16 dZ1[4];
-    mlp_layer<2, 4, 16, kH1>(N.W2, nullptr, 0, dZ2, dZ1, vo128, h);               // dH1 = W2^T dZ2
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) dZ1[t][r] *= fma_(-H1[t][r], H1[t][r], 1.0f);
+    mlp_layer<2, 4, 16, kH1, kEpiDtanh>(N.W2, nullptr, 0, dZ2, dZ1, vo128, h, H1); // dZ1 = (W2^T dZ2) (1 - H1^2)
     MLP_TK(3);
     // layer 1: dZ1 (128 rows), inputs = the observation tile (32 rows)
     __syncthreads();
@@ -330,60 +366,131 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     if ((wave & 1) == 0) { slab[kAccW2 + (32 * (wave >> 1) + nn) * 129 + 128] = gb2; slab[kAccW3 + (32 * (wave >> 1) + nn) * 65 + 64] = gb3; }
     if (wave == 0) slab[kAccW4 + nn * 65 + 64] = gb4;
   }
-  // per-lane loss sums -> the stats slots (d log_std[0..A), policy, value, clip count); LDS adds, then one writer
-  if (net == 0) {
+  // per-lane loss sums -> the stats slots (d log_std[0..A), policy, value, clip count): a butterfly over the 32 lanes of each half, one
+  // LDS slot per wavefront, then a fixed-order sum over the wavefronts -- deterministic like the rest
+  {
+    float vals[7] = {s_dls[0], s_dls[1], s_dls[2], s_dls[3], s_pol, s_val, s_clipn};
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (r + 4 * h < A) atomicAdd(&lstats[r + 4 * h], s_dls[r]);
-    atomicAdd(&lstats[8], s_pol); atomicAdd(&lstats[10], s_clipn);
-  } else atomicAdd(&lstats[9], s_val);
+    for (int k = 0; k < 7; k++)
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) vals[k] += __shfl_xor(vals[k], o);
+    if (nn == 0) {
+      float* ws_ = lstats + 16 * wave;
+      if (net == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) ws_[r + 4 * h] = vals[r];
+        if (h == 0) { ws_[8] = vals[4]; ws_[10] = vals[6]; }
+      } else if (h == 0) ws_[9] = vals[5];
 #ifdef AMENV_MLP_STAMPS
-  if (lane == 0) for (int k = 0; k < 4; k++) atomicAdd(&lstats[11 + k], tph[k]);
+      if (h == 0) for (int k = 0; k < 4; k++) ws_[11 + k] = tph[k];
 #endif
+    }
+  }
   __syncthreads();
-  if (threadIdx.x < 16) slab[kAccStats + threadIdx.x] = lstats[threadIdx.x];
+  if (threadIdx.x < 16) slab[kAccStats + threadIdx.x] = ((lstats[threadIdx.x] + lstats[16 + threadIdx.x]) + lstats[32 + threadIdx.x]) + lstats[48 + threadIdx.x];
 }
 
 // Fixed-order sum of the per-workgroup slabs into the flat gradient (SB3 parameter order) + d log_std + the four reported scalars.
-// One thread per parameter (+ 4 for the stats).
-__global__ void mlp_grad_reduce_kernel(const float* __restrict__ part, int blocks, int D, int A, int64_t n, const float* __restrict__ Pm, float ent_coef,
-                                       float* __restrict__ grad, float* __restrict__ stats) {
+// 256 threads = 64 outputs x 4 slab groups: a wavefront reads 64 consecutive slots of one slab (coalesced), all loads of a group in
+// flight together; the four group sums meet in LDS and are added in group order.
+constexpr int kRedGroups = 4;
+__global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(const float* __restrict__ part, int blocks, int D, int A, int64_t n, const float* __restrict__ Pm,
+                                                              float ent_coef, float* __restrict__ grad, float* __restrict__ stats) {
+  __shared__ float sh[kRedGroups][64];
   const int trunk = kH1 * D + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;
   const int total = A + 2 * trunk + A * kH3 + A + kH3 + 1;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= total + 4) return;
-  auto sum = [&](int net, int slot) {
-    float t = 0.0f;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int tid = blockIdx.x * 64 + lane;
+  int net = 0, slot = -1;                                    // slot < 0: nothing to sum (entropy, out of range)
+  if (tid < A) slot = kAccStats + tid;
+  else if (tid < total) {
+    int e = tid - A;
+    if (e < 2 * trunk) {
+      net = e / trunk; e %= trunk;
+      if (e < kH1 * D) slot = kAccW1 + (e / D) * 33 + e % D;
+      else if ((e -= kH1 * D) < kH1) slot = kAccW1 + e * 33 + 32;
+      else if ((e -= kH1) < kH2 * kH1) slot = kAccW2 + (e / kH1) * 129 + e % kH1;
+      else if ((e -= kH2 * kH1) < kH2) slot = kAccW2 + e * 129 + 128;
+      else if ((e -= kH2) < kH3 * kH2) slot = kAccW3 + (e / kH2) * 65 + e % kH2;
+      else { e -= kH3 * kH2; slot = kAccW3 + e * 65 + 64; }
+    } else {
+      e -= 2 * trunk;
+      if (e < A * kH3) { net = 0; slot = kAccW4 + (e / kH3) * 65 + e % kH3; }
+      else if ((e -= A * kH3) < A) { net = 0; slot = kAccW4 + e * 65 + 64; }
+      else if ((e -= A) < kH3) { net = 1; slot = kAccW4 + e; }
+      else { net = 1; slot = kAccW4 + 64; }
+    }
+  } else if (tid < total + 4) {
+    const int k = tid - total;                               // policy loss, value loss, entropy loss, clip fraction
+    if (k == 0) slot = kAccStats + 8;
+    else if (k == 1) { net = 1; slot = kAccStats + 9; }
+    else if (k == 3) slot = kAccStats + 10;
+  }
+  float t = 0.0f;
+  if (slot >= 0) {
+    const int per = (blocks + kRedGroups - 1) / kRedGroups, b0 = grp * per, b1 = min(blocks, b0 + per);
     const float* p = part + size_t(net) * blocks * kAccSize + slot;
-    for (int b = 0; b < blocks; b++) t += p[size_t(b) * kAccSize];
-    return t;
-  };
-  if (tid >= total) {   // stats: policy loss, value loss, entropy loss, clip fraction
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = p[size_t(b + j) * kAccSize];
+#pragma unroll
+      for (int j = 0; j < 8; j++) t += v[j];
+    }
+    for (; b < b1; b++) t += p[size_t(b) * kAccSize];
+  }
+  sh[grp][lane] = t;
+  __syncthreads();
+  if (grp != 0 || tid >= total + 4) return;
+  t = 0.0f;
+#pragma unroll
+  for (int g = 0; g < kRedGroups; g++) t += sh[g][lane];
+  if (tid >= total) {
     const int k = tid - total;
-    if (k == 0) stats[0] = sum(0, kAccStats + 8) / float(n);
-    else if (k == 1) stats[1] = sum(1, kAccStats + 9) / float(n);
-    else if (k == 2) { float e = 0.0f; for (int j = 0; j < A; j++) e += 1.418938533204672742f + Pm[j]; stats[2] = -e; }
-    else stats[3] = sum(0, kAccStats + 10) / float(n);
-    return;
+    if (k == 2) { float e = 0.0f; for (int j = 0; j < A; j++) e += 1.418938533204672742f + Pm[j]; stats[2] = -e; }
+    else stats[k] = t / float(n);
+  } else grad[tid] = tid < A ? t - ent_coef : t;
+}
+
+// Gradient-norm clip + Adam on the flat parameter buffer in one launch (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam, the step SB3's
+// PPO.train() takes): every workgroup sums |scale * g|^2 over the whole buffer in the same order (so all agree on the norm), then
+// updates its slice.  `step` is torch's capturable-Adam step counter (a float on the device); the last workgroup to finish increments
+// it (ticket), after every workgroup has read it.
+// hyper: [0] lr  [1] beta1  [2] beta2  [3] eps  [4] max_grad_norm (<= 0: no clipping)  [5] grad_scale (1 / world size after a sum all-reduce)
+constexpr int kAdamBlock = 1024, kAdamMaxBlocks = 64;
+__global__ __launch_bounds__(kAdamBlock) void adam_clip_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                                               float* __restrict__ step, int64_t n, const float* __restrict__ hyper, float* __restrict__ grad_norm,
+                                                               unsigned int* __restrict__ ticket) {
+  __shared__ float sh[kAdamBlock / 64];
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], max_norm = hyper[4], scale = hyper[5];
+  const float t = step[0] + 1.0f;
+  float ss = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += kAdamBlock) { const float g = grad[i] * scale; ss = fma_(g, g, ss); }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float tot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kAdamBlock / 64; k++) tot += sh[k];
+  const float gn = sqrtf(tot);
+  const float coef = max_norm > 0.0f ? fminf(max_norm / (gn + 1e-6f), 1.0f) * scale : scale;
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x, i0 = int64_t(blockIdx.x) * per, i1 = i0 + per < n ? i0 + per : n;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += kAdamBlock) {
+    const float g = grad[i] * coef;
+    const float mi = fma_(g - m[i], 1.0f - b1, m[i]);                 // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fma_(g * g, 1.0f - b2, v[i] * b2);               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    grad[i] = g; m[i] = mi; v[i] = vi;
+    param[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
   }
-  if (tid < A) { grad[tid] = sum(0, kAccStats + tid) - ent_coef; return; }
-  int e = tid - A, net, slot;
-  if (e < 2 * trunk) {
-    net = e / trunk; e %= trunk;
-    if (e < kH1 * D) slot = kAccW1 + (e / D) * 33 + e % D;
-    else if ((e -= kH1 * D) < kH1) slot = kAccW1 + e * 33 + 32;
-    else if ((e -= kH1) < kH2 * kH1) slot = kAccW2 + (e / kH1) * 129 + e % kH1;
-    else if ((e -= kH2 * kH1) < kH2) slot = kAccW2 + e * 129 + 128;
-    else if ((e -= kH2) < kH3 * kH2) slot = kAccW3 + (e / kH2) * 65 + e % kH2;
-    else { e -= kH3 * kH2; slot = kAccW3 + e * 65 + 64; }
-  } else {
-    e -= 2 * trunk;
-    if (e < A * kH3) { net = 0; slot = kAccW4 + (e / kH3) * 65 + e % kH3; }
-    else if ((e -= A * kH3) < A) { net = 0; slot = kAccW4 + e * 65 + 64; }
-    else if ((e -= A) < kH3) { net = 1; slot = kAccW4 + e; }
-    else { net = 1; slot = kAccW4 + 64; }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && grad_norm) grad_norm[0] = gn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) { step[0] = t; *ticket = 0u; }
   }
-  grad[tid] = sum(net, slot);
 }
 
 }  // namespace amenv_dev

@@ -103,11 +103,12 @@ constexpr int kPpoBlock = 256;
 constexpr int kPpoMaxBlocks = 1024;
 constexpr int kPpoPartial = AMENV_MAX_JOINTS + kActDim + 4;   // d log_std[<=7] + policy / value / clip-fraction sums (+1 spare)
 
-__global__ __launch_bounds__(kPpoBlock) void ppo_adv_partials(const float* __restrict__ adv, int64_t n, double* __restrict__ part) {
+__global__ __launch_bounds__(kPpoBlock) void ppo_adv_partials(const float* __restrict__ adv, int64_t n, double* __restrict__ part,
+                                                              const int64_t* __restrict__ index = nullptr) {
   __shared__ double sh[2][kPpoBlock / 64];
   double s = 0.0, q = 0.0;
   for (int64_t i = int64_t(blockIdx.x) * kPpoBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kPpoBlock) {
-    const double a = adv[i];
+    const double a = adv[index ? index[i] : i];
     s += a; q += a * a;
   }
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); q += __shfl_down(q, o); }

@@ -299,6 +299,12 @@ class MinibatchStep:
         ok = dev.type == "cuda" and getattr(policy, "net_arch", None) == (128, 64, 64) and (policy.obs_dim, policy.act_dim) in policy._FUSED_DIMS
         self.fused_mlp = ok if fused_mlp is None else (bool(fused_mlp) and ok)
         self._mlp_ws = None
+        # clip + Adam in one launch on torch.optim.Adam's own state tensors (amenv_ppo_adam_step) where the optimiser is the plain Adam
+        # on the flat buffer that `PPO` builds; anything else steps through torch
+        self.fused_adam = self.fused_mlp and self._adam_is_plain(optimizer, policy)
+        self._adam_hyper = self._adam_key = self._adam_ticket = None
+        if self.fused_mlp and use_graph is None:
+            self.use_graph = False                       # five launches per minibatch: nothing left for a graph to save
         self._static = None
         self._graphs = None
         self._eager_calls = 0
@@ -346,16 +352,28 @@ class MinibatchStep:
         grads = torch.autograd.grad([mean, values], self._net_params, grad_outputs=[d_mean, d_value])
         torch.cat([d_log_std] + [g.reshape(-1) for g in grads], out=pol.flat_grad)     # log_std is the first parameter
 
-    def _forward_backward_mlp(self, obs, actions, old_logp, adv, ret):
+    @staticmethod
+    def _adam_is_plain(opt, policy):
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1 or len(opt.param_groups[0]["params"]) != 1:
+            return False
+        g = opt.param_groups[0]
+        p = g["params"][0]
+        return (p.data_ptr() == policy.flat_param.data_ptr() and p.numel() == policy.flat_param.numel() and g.get("capturable", False)
+                and not g.get("amsgrad") and not g.get("maximize") and g.get("weight_decay", 0) == 0 and not g.get("decoupled_weight_decay", False)
+                and not isinstance(g["lr"], torch.Tensor))
+
+    def _forward_backward_mlp(self, obs, actions, old_logp, adv, ret, index=None):
         """Forward, SB3's loss, backward and every weight gradient in ONE kernel (csrc/amenv_mlp_train.hpp): the gradient lands in the flat
-        buffer, the four reported scalars in `stats`.  fp32 throughout (v_mfma_f32_32x32x2_f32), autograd is not involved."""
+        buffer, the four reported scalars in `stats`.  fp32 throughout (v_mfma_f32_32x32x2_f32), autograd is not involved.  With `index`
+        (int64 [n]) the minibatch is rows `index` of the given tensors, gathered inside the kernel."""
         pol = self.policy
         if self._mlp_ws is None:
             self._mlp_ws = torch.empty(L.load().amenv_ppo_mlp_workspace_bytes() // 8 + 2, dtype=torch.float64, device=obs.device)
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         obs, actions = obs.contiguous(), actions.contiguous()
-        rc = L.load().amenv_ppo_mlp_step(p(pol.flat_param.detach()), pol.obs_dim, pol.act_dim, p(obs), p(actions), p(old_logp), p(adv), p(ret), obs.shape[0],
-                                         self.clip_range, self.ent_coef, self.vf_coef, 1 if self.normalize_advantage else 0, p(pol.flat_grad), p(self.stats),
+        n = obs.shape[0] if index is None else index.shape[0]
+        rc = L.load().amenv_ppo_mlp_step(p(pol.flat_param.detach()), pol.obs_dim, pol.act_dim, p(obs), p(actions), p(old_logp), p(adv), p(ret),
+                                         None if index is None else p(index), n, self.clip_range, self.ent_coef, self.vf_coef, 1 if self.normalize_advantage else 0, p(pol.flat_grad), p(self.stats),
                                          p(self._mlp_ws), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
         if rc != 0:
             raise L.AmenvError(f"amenv_ppo_mlp_step failed ({rc})")
@@ -363,10 +381,37 @@ class MinibatchStep:
     def _exchange(self):
         if self.dist is not None and (self.world > 1 or self.split):
             self.dist.all_reduce(self.policy.flat_grad)
-            if self.world > 1:
+            if self.world > 1 and not self.fused_adam:   # (the fused Adam step folds 1 / world into its gradient scale)
                 self.policy.flat_grad.div_(self.world)
 
+    def _apply_fused(self):
+        """Clip + Adam as one launch on the optimiser's own state (so `optimizer.state_dict()` and checkpoints stay torch's)."""
+        opt, pol = self.optimizer, self.policy
+        g = opt.param_groups[0]
+        leaf = g["params"][0]
+        st = opt.state[leaf]
+        if not st:                                       # torch.optim.Adam creates its state on the first step
+            st["step"] = torch.zeros((), dtype=torch.float32, device=leaf.device)
+            st["exp_avg"] = torch.zeros_like(pol.flat_param)
+            st["exp_avg_sq"] = torch.zeros_like(pol.flat_param)
+        key = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+               float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0, 1.0 / self.world)
+        if key != self._adam_key:
+            if self._adam_hyper is None:
+                self._adam_hyper = torch.empty(6, dtype=torch.float32, device=leaf.device)
+                self._adam_ticket = torch.zeros(1, dtype=torch.int32, device=leaf.device)
+            self._adam_hyper.copy_(torch.tensor(key, dtype=torch.float32))
+            self._adam_key = key
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = L.load().amenv_ppo_adam_step(p(pol.flat_param.detach()), p(pol.flat_grad), p(st["exp_avg"]), p(st["exp_avg_sq"]), p(st["step"]), pol.flat_param.numel(),
+                                          p(self._adam_hyper), C.c_void_p(self.stats.data_ptr() + 16), p(self._adam_ticket),
+                                          C.c_void_p(torch.cuda.current_stream(leaf.device).cuda_stream))
+        if rc != 0:
+            raise L.AmenvError(f"amenv_ppo_adam_step failed ({rc})")
+
     def _apply(self):
+        if self.fused_adam:
+            return self._apply_fused()
         g = self.policy.flat_grad
         gn = g.norm(2)
         if self.max_grad_norm is not None:
@@ -376,6 +421,12 @@ class MinibatchStep:
 
     def _eager(self, *mb):
         self._forward_backward(*mb)
+        self._exchange()
+        self._apply()
+
+    def indexed(self, obs, actions, old_logp, adv, ret, index):
+        """One minibatch step on rows `index` of the whole-rollout tensors (fused path only): no gathered copies, no graph."""
+        self._forward_backward_mlp(obs, actions, old_logp, adv, ret, index)
         self._exchange()
         self._apply()
 
@@ -440,10 +491,15 @@ def ppo_update(policy, optimizer, obs, actions, old_logp, advantages, returns, *
     for epoch in range(n_epochs):
         # one shuffle of the whole buffer per epoch (5 gathers), then every minibatch is a contiguous slice
         perm = torch.randperm(n, device=obs.device, generator=generator)
-        obs_s, act_s, olp_s, adv_s, ret_s = obs[perm], actions[perm], old_logp[perm], advantages[perm], returns[perm]
+        indexed = step.fused_mlp and not step.use_graph
+        if not indexed:
+            obs_s, act_s, olp_s, adv_s, ret_s = obs[perm], actions[perm], old_logp[perm], advantages[perm], returns[perm]
         for start in range(0, n, batch_size):
             sl = slice(start, min(start + batch_size, n))
-            step(obs_s[sl], act_s[sl], olp_s[sl], adv_s[sl], ret_s[sl])
+            if indexed:                                  # the kernel reads rows perm[sl] itself
+                step.indexed(obs, actions, old_logp, advantages, returns, perm[sl])
+            else:
+                step(obs_s[sl], act_s[sl], olp_s[sl], adv_s[sl], ret_s[sl])
             if epoch == n_epochs - 1:   # losses are reported for the last epoch only (no host sync inside the loop)
                 total += step.stats
                 n_batches += 1
@@ -458,7 +514,7 @@ class PPO:
 
     def __init__(self, env, policy=None, learning_rate=2e-4, n_steps=2048, batch_size=128, n_epochs=12, gamma=0.995,
                  gae_lambda=0.9, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5, normalize_advantage=True,
-                 net_arch=(128, 64, 64), seed=0, obs_normalizer=None, bootstrap_truncated=True, dist=None, use_graph=None, fused_rollout=False):
+                 net_arch=(128, 64, 64), seed=0, obs_normalizer=None, bootstrap_truncated=True, dist=None, use_graph=None, fused_rollout=False, fused_mlp=None):
         if env.state_dtype != torch.float32:
             raise L.AmenvError("PPO needs the fp32 environment")
         self.env, self.dist = env, dist
@@ -482,7 +538,7 @@ class PPO:
         self.optimizer = torch.optim.Adam([self._leaf], lr=learning_rate, eps=1e-5, capturable=self.device.type == "cuda")
         self._step = MinibatchStep(self.policy, self.optimizer, clip_range=self.clip_range, ent_coef=self.ent_coef, vf_coef=self.vf_coef,
                                    max_grad_norm=self.max_grad_norm, normalize_advantage=self.normalize_advantage,
-                                   dist=dist if self.world > 1 else None, use_graph=use_graph)
+                                   dist=dist if self.world > 1 else None, use_graph=use_graph, fused_mlp=fused_mlp)
         self.obs_normalizer = obs_normalizer
         self.buffer = RolloutBuffer(self.n_steps, env.num_envs, env.obs_dim, env.act_dim, self.device)
         self._clipped = torch.zeros(env.num_envs, env.act_dim, dtype=torch.float32, device=self.device)

@@ -490,3 +490,96 @@ def test_fused_mlp_step_matches_autograd(D, A, n):
         off += k
     assert torch.allclose(s0, s1, rtol=2e-4, atol=1e-6), (s0, s1)
     assert 0.02 < float(s1[3]) < 0.9                                       # clip fraction: the clipped branch was exercised
+
+
+def _mlp_problem(D, A, n, seed=1):
+    torch.manual_seed(3)
+    pol = ActorCritic(D, A).cuda().flatten_()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    obs = torch.randn(n, D, device="cuda", generator=g) * 0.7
+    actions = torch.randn(n, A, device="cuda", generator=g) * 0.5
+    with torch.no_grad():
+        _, logp, _ = pol.evaluate_actions(obs, actions)
+    old_logp = logp + 0.15 * torch.randn(n, device="cuda", generator=g)
+    adv = torch.randn(n, device="cuda", generator=g) * 3.0 + 0.5
+    ret = torch.randn(n, device="cuda", generator=g) * 2.0
+    return pol, (obs, actions, old_logp, adv, ret)
+
+
+def test_fused_mlp_step_index_gather_is_bit_identical_and_deterministic():
+    """`index` makes the kernel read rows index[s] of the rollout tensors: the gradient equals, bit for bit, the one from the gathered
+    copies; and the step has no atomics on the gradient path, so a repeated call gives the same bits."""
+    from rl_aerial_manipulator_amd.ppo import MinibatchStep
+    n_roll, n = 50000, 12345
+    pol, full = _mlp_problem(29, 7, n_roll)
+    opt = torch.optim.Adam([pol.flat_param.requires_grad_(True)], lr=1e-3, capturable=True)
+    step = MinibatchStep(pol, opt, use_graph=False)
+    assert step.fused_mlp
+    idx = torch.randperm(n_roll, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))[:n]
+    step._forward_backward_mlp(*full, idx)
+    g_idx, s_idx = pol.flat_grad.clone(), step.stats[:4].clone()
+    step._forward_backward_mlp(*[t[idx].contiguous() for t in full])
+    g_cpy, s_cpy = pol.flat_grad.clone(), step.stats[:4].clone()
+    assert torch.equal(g_idx, g_cpy) and torch.equal(s_idx, s_cpy)
+    step._forward_backward_mlp(*full, idx)
+    assert torch.equal(pol.flat_grad, g_idx)
+    assert float(g_idx.abs().max()) > 0
+
+
+@pytest.mark.parametrize("world_scale,max_norm", [(1, 0.5), (2, 0.5), (1, None)])
+def test_fused_adam_step_matches_torch_adam(world_scale, max_norm):
+    """amenv_ppo_adam_step against clip_grad_norm_-style scaling + torch.optim.Adam over several steps: parameters, both moments, the
+    step counter and the reported norm."""
+    from rl_aerial_manipulator_amd import _lib as L_
+    import ctypes as C_
+    torch.manual_seed(0)
+    n = 33039
+    p_ref = torch.randn(n, device="cuda", dtype=torch.float64) * 0.3
+    p_hip = p_ref.float().clone()
+    leaf = p_ref.clone().requires_grad_(True)
+    opt = torch.optim.Adam([leaf], lr=2e-4, eps=1e-5)
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda"); stp = torch.zeros((), device="cuda")
+    hyper = torch.tensor([2e-4, 0.9, 0.999, 1e-5, max_norm or 0.0, 1.0 / world_scale], device="cuda")
+    gn = torch.zeros(1, device="cuda"); ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ptr = lambda t: C_.c_void_p(t.data_ptr())  # noqa: E731
+    for it in range(25):
+        g = torch.randn(n, device="cuda") * (0.05 if it % 3 else 0.001) * world_scale
+        gd = g.double() / world_scale
+        norm = gd.norm(2)
+        if max_norm is not None:
+            gd = gd * torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        leaf.grad = gd.clone()
+        opt.step()
+        gh = g.clone()
+        rc = L_.load().amenv_ppo_adam_step(ptr(p_hip), ptr(gh), ptr(m), ptr(v), ptr(stp), n, ptr(hyper), ptr(gn), ptr(ticket), None)
+        assert rc == 0
+        assert abs(float(gn) - float(norm)) < 1e-5 * float(norm)
+        assert torch.allclose(gh.double(), gd, rtol=1e-5, atol=1e-9)
+    st = opt.state[leaf]
+    assert float(stp) == 25.0 and int(ticket) == 0
+    assert torch.allclose(m.double(), st["exp_avg"], rtol=1e-4, atol=1e-7)
+    assert torch.allclose(v.double(), st["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    # 25 Adam steps of at most lr each: the fp32 kernel tracks the fp64 optimiser to a small fraction of one step
+    assert float((p_hip.double() - leaf.detach()).abs().max()) < 2e-4 * 0.02
+    assert float((p_hip.double() - p_ref).abs().max()) > 1e-3
+
+
+def test_ppo_update_fused_path_trains_like_the_torch_path():
+    """`ppo_update` with the fused MLP + Adam kernels (indexed minibatches, no graph) against the same update through the torch modules
+    and torch.optim.Adam, same permutations: parameters after 2 epochs x 4 minibatches agree to fp32 round-off of a few Adam steps."""
+    from rl_aerial_manipulator_amd.ppo import MinibatchStep, ppo_update
+    res = []
+    for fused in (False, True):
+        pol, data = _mlp_problem(29, 7, 16384)
+        opt = torch.optim.Adam([pol.flat_param.requires_grad_(True)], lr=2e-4, eps=1e-5, capturable=True)
+        pol.flat_param.grad = pol.flat_grad
+        step = MinibatchStep(pol, opt, use_graph=False, fused_mlp=fused)
+        assert step.fused_mlp == fused and step.fused_adam == fused
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        out = ppo_update(pol, opt, *data, batch_size=4096, n_epochs=2, generator=gen, step=step)
+        res.append((pol.flat_param.detach().clone(), out, float(opt.state[opt.param_groups[0]["params"][0]]["step"])))
+    (p0, o0, t0), (p1, o1, t1) = res
+    assert t0 == t1 == 8.0
+    assert float((p0 - p1).abs().max()) < 0.05 * 8 * 2e-4, float((p0 - p1).abs().max())
+    for k in o0:
+        assert abs(o0[k] - o1[k]) <= 2e-3 * max(abs(o0[k]), 1e-3), (k, o0[k], o1[k])

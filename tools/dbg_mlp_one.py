@@ -11,7 +11,7 @@ adv = torch.randn(n, device="cuda"); ret = torch.randn(n, device="cuda")
 step = MinibatchStep(pol, opt, use_graph=False, fused_mlp=True)
 for _ in range(10): step._forward_backward(obs, actions, olp, adv, ret)
 torch.cuda.synchronize()
-if os.environ.get("AMENV_LIB", "").endswith("mlpstamps.so"):
+if "mlpstamps" in os.environ.get("AMENV_LIB", ""):
     import numpy as np
     ws = step._mlp_ws.view(torch.float32)
     adv_b, wt = 2 * 1024 * 2, 2 * (32*128 + 128*64 + 64*64 + 64*32 + 32*64)
