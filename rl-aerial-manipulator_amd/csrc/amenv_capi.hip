@@ -984,7 +984,7 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
   if (st != hipSuccess) return AMENV_ERR_HIP;
   const int trunk = kH1 * obs_dim + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;
   const int total = act_dim + 2 * trunk + act_dim * kH3 + act_dim + kH3 + 1;
-  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((total + 4 + 63) / 64), dim3(256), 0, s, (const float*)part, blocks, (int)obs_dim, (int)act_dim, (int64_t)n, flat_params,
+  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((total + 4 + 63) / 64), dim3(64 * kRedGroups), 0, s, (const float*)part, blocks, (int)obs_dim, (int)act_dim, (int64_t)n, flat_params,
                      ent_coef, flat_grad, stats4);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }

@@ -391,10 +391,10 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
 }
 
 // Fixed-order sum of the per-workgroup slabs into the flat gradient (SB3 parameter order) + d log_std + the four reported scalars.
-// 256 threads = 64 outputs x 4 slab groups: a wavefront reads 64 consecutive slots of one slab (coalesced), all loads of a group in
-// flight together; the four group sums meet in LDS and are added in group order.
-constexpr int kRedGroups = 4;
-__global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(const float* __restrict__ part, int blocks, int D, int A, int64_t n, const float* __restrict__ Pm,
+// 512 threads = 64 outputs x 8 slab groups: a wavefront reads 64 consecutive slots of one slab (coalesced), the (up to 16) loads of its
+// group in flight together; the group sums meet in LDS and are added in group order.
+constexpr int kRedGroups = 8;
+__global__ __launch_bounds__(64 * kRedGroups) void mlp_grad_reduce_kernel(const float* __restrict__ part, int blocks, int D, int A, int64_t n, const float* __restrict__ Pm,
                                                               float ent_coef, float* __restrict__ grad, float* __restrict__ stats) {
   __shared__ float sh[kRedGroups][64];
   const int trunk = kH1 * D + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;
@@ -431,12 +431,12 @@ __global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(const float* __res
     const int per = (blocks + kRedGroups - 1) / kRedGroups, b0 = grp * per, b1 = min(blocks, b0 + per);
     const float* p = part + size_t(net) * blocks * kAccSize + slot;
     int b = b0;
-    for (; b + 8 <= b1; b += 8) {
-      float v[8];
+    for (; b + 16 <= b1; b += 16) {
+      float v[16];
 #pragma unroll
-      for (int j = 0; j < 8; j++) v[j] = p[size_t(b + j) * kAccSize];
+      for (int j = 0; j < 16; j++) v[j] = p[size_t(b + j) * kAccSize];
 #pragma unroll
-      for (int j = 0; j < 8; j++) t += v[j];
+      for (int j = 0; j < 16; j++) t += v[j];
     }
     for (; b < b1; b++) t += p[size_t(b) * kAccSize];
   }
@@ -466,7 +466,17 @@ __global__ __launch_bounds__(kAdamBlock) void adam_clip_kernel(float* __restrict
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], max_norm = hyper[4], scale = hyper[5];
   const float t = step[0] + 1.0f;
   float ss = 0.0f;
-  for (int64_t i = threadIdx.x; i < n; i += kAdamBlock) { const float g = grad[i] * scale; ss = fma_(g, g, ss); }
+  {
+    int64_t i = threadIdx.x;
+    for (; i + 7 * kAdamBlock < n; i += 8 * kAdamBlock) {     // eight loads in flight; the sum order is fixed by (thread, i)
+      float g[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) g[j] = grad[i + j * kAdamBlock] * scale;
+#pragma unroll
+      for (int j = 0; j < 8; j++) ss = fma_(g[j], g[j], ss);
+    }
+    for (; i < n; i += kAdamBlock) { const float g = grad[i] * scale; ss = fma_(g, g, ss); }
+  }
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
   __syncthreads();
