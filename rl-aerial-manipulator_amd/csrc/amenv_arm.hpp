@@ -137,7 +137,9 @@ __device__ __forceinline__ V3<T> ee_offset_world_any(const ArmParams<T>& A, T qw
 // terms), the main wave the base, links 1-2, the 3x3 solve.  They meet twice per RHS through LDS: helper -> main 21 partial sums,
 // main -> helper the 6 solved accelerations.  The partials are added in the order the one-wave code adds them, so both variants
 // (and the rollout kernel) give bit-identical trajectories.
-enum { ARM_ROLE_ALL = 0, ARM_ROLE_MAIN = 1, ARM_ROLE_HELPER = 2, ARM_ROLE_WORDS = 3 };   // WORDS: rigid kernels whose reset words come from a helper wave
+// WORDS: rigid kernels whose reset words come from a helper wave; FLAGS: rigid kernel whose helper waves do ALL episode-end work (the main
+// wave only reports which lanes ended)
+enum { ARM_ROLE_ALL = 0, ARM_ROLE_MAIN = 1, ARM_ROLE_HELPER = 2, ARM_ROLE_WORDS = 3, ARM_ROLE_FLAGS = 4 };
 constexpr int kArmPreSlot = 27;     // link 2's body-frame kinematics of the NEXT stage, precomputed by the helper: r u a_ (9) J (6) w al (6)
 constexpr int kArmXchgSlots = 48;   // 21 partial sums + wd(3) + vd(3) + 21 precomputed, [slot][64 lanes] floats
 // Chain quantities behind joint 2 (rotation, position / velocity / acceleration of the joint-3 origin, angular velocity / acceleration

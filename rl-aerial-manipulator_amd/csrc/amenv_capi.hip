@@ -384,7 +384,7 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   }
   if constexpr (NJ == 0) {
     if (T_steps == 0 && e.pwave) {   // one tile per 128-thread workgroup: main wave + reset-RNG wave
-      const dim3 g2(e.n_tiles), b2((KW == 1 && VAR == VAR_V2) ? 192 : 128);   // + an observation wave for the single-waypoint v2 task
+      const dim3 g2(e.n_tiles), b2((KW == 1 && VAR == VAR_V2) ? 256 : 128);   // + observation and Monitor waves for the single-waypoint v2 task
       const size_t lds2 = size_t(64 * ObsDim<VAR, 0>::value + 12 * 64) * sizeof(float);
       if (timed) hipExtLaunchKernelGGL((step_kernel_pw<T, NROT, KW, VAR>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
                                        io.done, io.info, tl, P, C);
@@ -586,10 +586,11 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     e->arm2w = !ap.generic_axes && (want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 65536 : want == AMENV_KERNEL_HELPER);
   }
   if (cfg->vehicle.n_joints == 0 && cfg->block_size == 0)
-    e->pwave = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 32768 : want == AMENV_KERNEL_HELPER;
+    e->pwave = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 32768 : (want == AMENV_KERNEL_HELPER && cfg->num_envs <= 64 * kStatsReplicas);
   if (want == AMENV_KERNEL_HELPER && !e->arm2w && !e->pwave) {
     amenv_destroy(e);
-    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_HELPER is built for fp32 z,x,x-arm vehicles and for rigid vehicles with block_size = 0");
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_HELPER is built for fp32 z,x,x-arm vehicles and for rigid vehicles with block_size = 0 "
+                "and at most 65536 envs (its Monitor wave owns one of the 1024 replicas of the running totals per tile)");
   }
   // lane-team kernel (16 lanes per env): one wavefront per SIMD up to 4096 envs; measured against the two-wave kernel on MI355X:
   // 5.9 vs 7.7 us at 2048 envs, 6.1 vs 7.8 at 4096, 9.0 vs 7.9 at 8192 (two team wavefronts per SIMD) -> AUTO up to 6144 envs
@@ -617,7 +618,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     }
   }
   char buf[200];
-  if (e->pwave) std::snprintf(buf, sizeof(buf), "step_kernel_pw<%s,NROT=%d,KW=%d,%s> (main wave + reset-RNG wave [+ observation wave] per 64-env tile)",
+  if (e->pwave) std::snprintf(buf, sizeof(buf), "step_kernel_pw<%s,NROT=%d,KW=%d,%s> (main wave + reset wave [+ observation wave + Monitor wave] per 64-env tile)",
                               cfg->dtype == AMENV_F64 ? "double" : "float",
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
@@ -1012,7 +1013,8 @@ __global__ void touch_kernel(void* blob, uint32_t tile_bytes, int32_t n, unsigne
 int amenv_debug_noop(amenv* e, int which, int block, void* stream) {
   DeviceGuard g(e->device);
   const int bs = block > 0 ? block : e->block, n_pad = e->n_tiles * 64;
-  if (which == 0) hipLaunchKernelGGL(noop_kernel, dim3((n_pad + bs - 1) / bs), dim3(bs), 0, (hipStream_t)stream, e->blob, e->tile_bytes, e->cfg.num_envs, e->stats);
+  if (which >= 2) hipLaunchKernelGGL(noop_kernel, dim3(which), dim3(bs), 0, (hipStream_t)stream, e->blob, e->tile_bytes, e->cfg.num_envs, e->stats);   // explicit grid
+  else if (which == 0) hipLaunchKernelGGL(noop_kernel, dim3((n_pad + bs - 1) / bs), dim3(bs), 0, (hipStream_t)stream, e->blob, e->tile_bytes, e->cfg.num_envs, e->stats);
   else hipLaunchKernelGGL(touch_kernel, dim3((n_pad + bs - 1) / bs), dim3(bs), 0, (hipStream_t)stream, e->blob, e->tile_bytes, e->cfg.num_envs, e->stats);
   AMENV_HIP(e, hipGetLastError());
   return AMENV_OK;

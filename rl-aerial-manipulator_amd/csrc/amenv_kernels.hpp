@@ -198,6 +198,23 @@ __device__ __forceinline__ void accumulate_stats(unsigned long long* __restrict_
   }
 }
 
+// The same totals from inside a divergent "this lane's episode ended" branch: every ended lane adds its own episode with five no-return
+// atomics (integer: the sums do not depend on the order).  No ballots, no scalar loop -- ~30 instructions: the episode-end code of a
+// wavefront is rarely executed on any one CU, so its cost is instruction-cache misses and what counts is its size.
+__device__ __forceinline__ void accumulate_stats_lane(unsigned long long* __restrict__ stats_base, int wave_index, uint32_t bits, int ep_len, float ep_ret) {
+#ifdef AMENV_DIAG_NO_STATS
+  return;
+#endif
+  unsigned long long* stats = stats_base + size_t(wave_index & (kStatsReplicas - 1)) * kStatsStride;
+  atomicAdd(&stats[S_EPISODES], 1ull);
+  atomicAdd(&stats[(bits & AMENV_INFO_TERMINATED) ? S_TERMINATED : S_TRUNCATED], 1ull);
+  // at most one of the four causes is set (task_step / task_step_v1 return or chain them exclusively)
+  const int cause = (bits & AMENV_INFO_SUCCESS) ? S_SUCCESS : (bits & AMENV_INFO_CRASHED) ? S_CRASHED : (bits & AMENV_INFO_OOB) ? S_OOB : S_NONFINITE;
+  if (bits & (AMENV_INFO_SUCCESS | AMENV_INFO_CRASHED | AMENV_INFO_OOB | AMENV_INFO_NONFINITE)) atomicAdd(&stats[cause], 1ull);
+  atomicAdd(&stats[S_LENGTH], (unsigned long long)(long long)ep_len);
+  atomicAdd(&stats[S_RETURN_Q10], (unsigned long long)(__builtin_isfinite(ep_ret) ? (long long)__builtin_rintf(ep_ret * 1024.0f) : 0ll));
+}
+
 // The step/rollout kernels take what a wave needs before it can issue its first load as LEADING SCALAR
 // arguments (blob, tile_bytes, n, actions, obs, reward, done, info = 14 dwords): gfx950 preloads the
 // first 16 kernarg dwords into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16; struct
@@ -237,6 +254,28 @@ __device__ __forceinline__ void update_tool_offset(const ArmParams<T>& A, Env<T,
   e.eox = eo.x; e.eoy = eo.y; e.eoz = eo.z;
 }
 
+// Observation of a freshly reset env of the single-waypoint v2 task, written out: at rest, level, arm at home, one waypoint -- the same
+// values the general `observe` produces (its products with the zero velocities / rates are +0), ~12 instructions instead of ~130.
+template <typename T, int KW, bool EE, int NJ>
+__device__ __forceinline__ void observe_reset(const Env<T, KW>& e, bool ee_task, float* o) {
+  static_assert(KW == 1, "single-waypoint task");
+  const T c10 = T(0.1), c2 = T(0.5);
+  o[0] = float(e.px * c10); o[1] = float(e.py * c10); o[2] = float(e.pz * c10);
+  o[3] = o[4] = o[5] = 0.0f;
+  o[6] = 1.0f; o[7] = o[8] = o[9] = 0.0f;
+  o[10] = o[11] = o[12] = 0.0f;
+  T tx, ty, tz;
+  task_point<EE>(e, ee_task, tx, ty, tz);
+  o[13] = float((e.wp[0][0] - tx) * c2); o[14] = float((e.wp[0][1] - ty) * c2); o[15] = float((e.wp[0][2] - tz) * c2);
+  o[16] = o[17] = o[18] = 0.0f;
+  o[19] = float(e.final_yaw * T(0.31830988618379067154));
+  if constexpr (NJ > 0) {
+#pragma unroll
+    for (int k = 0; k < 2 * AMENV_MAX_JOINTS; k++) o[20 + k] = 0.0f;
+    o[26] = float(e.eox * T(2)); o[27] = float(e.eoy * T(2)); o[28] = float(e.eoz * T(2));
+  }
+}
+
 template <typename T, int NROT, int KW, int VAR, int NJ, int ROLE = 0, typename X = NoXchg>
 __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const ColdParams& C, const ArmArg<T, NJ>& AA, Env<T, KW>& e, const float* act, int i,
                                               bool active, T& reward, float* o, const StepIO& io, char* tile, int lane,
@@ -256,7 +295,8 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   e.ep_return += reward;
   // two-wave kernel: the helper wave computes and publishes the observation of every lane; this (main) wave forms one only in the
   // cold path below (terminal observation / post-reset observation of the lanes whose episode ended)
-  constexpr bool kLazyObs = ROLE == ARM_ROLE_MAIN;
+  constexpr bool kColdElsewhere = ROLE == ARM_ROLE_FLAGS;   // helper waves write terminal / post-reset rows and the reset state
+  constexpr bool kLazyObs = ROLE == ARM_ROLE_MAIN || kColdElsewhere;
   auto obs_now = [&]() {
     if constexpr (VAR == VAR_V1) { observe_v1<T, KW>(P.raw_obs != 0, e, o); } else { observe<T, KW, EE>(K, e, o, ee_task); }
     if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
@@ -270,7 +310,8 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   if constexpr (kWordsFromLds) x.sync();   // two-wave kernels: the helper has left every lane's 12 reset words in LDS (every step: unconditional barrier)
   if (__ballot(ended) != 0ull) {  // wave-uniform: the whole cold path is skipped by waves with no episode end
     uint32_t r[12];
-    if constexpr (kWordsFromLds) {
+    if constexpr (kColdElsewhere) {
+    } else if constexpr (kWordsFromLds) {
 #pragma unroll
       for (int k = 0; k < 12; k++) r[k] = x.words[k * 64 + lane];
     } else {
@@ -289,38 +330,25 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
             for (int j = 0; j < OD; j++) t[j] = o[j];
           }
         }
-        if (io.ep_return) io.ep_return[i] = ep_ret_out;
-        if (io.ep_len) io.ep_len[i] = ep_len_out;
+        if constexpr (!kColdElsewhere) {
+          if (io.ep_return) io.ep_return[i] = ep_ret_out;
+          if (io.ep_len) io.ep_len[i] = ep_len_out;
+        }
       }
       if (resets) {
-        if constexpr (VAR == VAR_V1) { reset_from_words_v1<T, KW>(K, e, r); observe_v1<T, KW>(P.raw_obs != 0, e, o); }
+        if constexpr (kColdElsewhere) { (void)r; }
+        else if constexpr (VAR == VAR_V1) { reset_from_words_v1<T, KW>(K, e, r); observe_v1<T, KW>(P.raw_obs != 0, e, o); }
         else {
           reset_from_words<T, KW>(C, K, e, r);
           if constexpr (EE) { e.eox = AA.p.ee_home[0]; e.eoy = AA.p.ee_home[1]; e.eoz = AA.p.ee_home[2]; }   // level, arm at home
           if constexpr (KW == 1) {
-            // observation of a freshly reset env, written out: at rest, level, arm at home, one waypoint -- the same values the general
-            // `observe` produces (its products with the zero velocities / rates are +0), ~12 instructions instead of ~130 on the cold path
-            const T c10 = T(0.1), c2 = T(0.5);
-            o[0] = float(e.px * c10); o[1] = float(e.py * c10); o[2] = float(e.pz * c10);
-            o[3] = o[4] = o[5] = 0.0f;
-            o[6] = 1.0f; o[7] = o[8] = o[9] = 0.0f;
-            o[10] = o[11] = o[12] = 0.0f;
-            T tx, ty, tz;
-            task_point<EE>(e, ee_task, tx, ty, tz);
-            o[13] = float((e.wp[0][0] - tx) * c2); o[14] = float((e.wp[0][1] - ty) * c2); o[15] = float((e.wp[0][2] - tz) * c2);
-            o[16] = o[17] = o[18] = 0.0f;
-            o[19] = float(e.final_yaw * T(0.31830988618379067154));
-            if constexpr (NJ > 0) {
-#pragma unroll
-              for (int k = 0; k < 2 * AMENV_MAX_JOINTS; k++) o[20 + k] = 0.0f;
-              o[26] = float(e.eox * T(2)); o[27] = float(e.eoy * T(2)); o[28] = float(e.eoz * T(2));
-            }
+            observe_reset<T, KW, EE, NJ>(e, ee_task, o);
           } else {
             observe<T, KW, EE>(K, e, o, ee_task);
             if constexpr (NJ > 0) observe_joints<T, KW>(e, o);
           }
         }
-        if constexpr (NJ > 0 && VAR == VAR_V1) observe_joints<T, KW>(e, o);
+        if constexpr (NJ > 0 && VAR == VAR_V1 && !kColdElsewhere) observe_joints<T, KW>(e, o);
         bits |= AMENV_INFO_WAS_RESET;
         was_reset = true;
       }
@@ -428,86 +456,205 @@ __global__ __launch_bounds__(256) AMENV_STEP_WAVES_ATTR void step_kernel(void* _
 #endif
 }
 
-// Rigid vehicles at small batches: a second wave per 64-env tile does nothing but the reset RNG.  With 4096 envs some tile ends an
-// episode in almost every launch and the launch is as slow as its slowest wave; the 12 Philox words of a reset depend only on (seed,
-// env id, episode), so the helper computes them for every lane while the main wave integrates, and the main wave's cold path starts from
-// the words in LDS (hover-only actions, which end no episode, ran 1.1 us faster than the bench workload before this).
-// For the single-waypoint v2 task (observation = pure function of the post-step state) a third wave integrates the same step only to
-// compute, stage and flush the observation rows, as the arm kernel's helper does: the main wave is left with dynamics + task step + stores.
+// Rigid vehicles at small batches: helper waves per 64-env tile take the episode-end work off the wave that integrates.  With 4096 envs
+// some tile ends an episode in almost every launch and the launch is as slow as its slowest wave (hover-only actions, which end no
+// episode, ran 1.1 us faster than the bench workload with a one-wave kernel).
+//  * KW > 1 or the v1 tasks (128 threads): wave 1 computes the 12 Philox words of a reset for every lane -- they depend only on (seed,
+//    env id, episode) -- while the main wave integrates; the main wave's cold path starts from the words in LDS.
+//  * single-waypoint v2 task (256 threads; the observation is a pure function of the post-step state).  Episode-end code runs rarely on
+//    any one CU and costs ~7 clocks per instruction there, so it is cut into pieces that run side by side after the ONE barrier:
+//      wave 3 loads the tile's replica of the running totals (it owns that replica for the launch); after the barrier it sums the
+//             contributions of the lanes that ended in LDS and stores the replica back: no global atomics (five same-line atomics took
+//             ~670 clocks to drain);
+//      wave 2 integrates the same step only to compute, stage and flush the observation rows (as the arm kernel's helper does) and keeps
+//             its rows in registers; after the barrier it writes the terminal-observation rows and Monitor's return / length of the
+//             lanes that ended;
+//      wave 1 computes, for EVERY lane, the words, the reset state and its observation, and leaves the reset position / final yaw in
+//             LDS; after the barrier it writes waypoint and observation row of the lanes that were reset;
+//      wave 0 (main) integrates, runs the task step, publishes a flag word per lane (and info bits / length / return of the lanes that
+//             ended), passes the barrier, takes the reset position of reset lanes from LDS and stores the state of every lane.
 template <typename T, int NROT, int KW, int VAR>
-__global__ __launch_bounds__(192) void step_kernel_pw(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+__global__ __launch_bounds__(256) void step_kernel_pw(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
                                                       float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
                                                       uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C) {
   constexpr int OD = ObsDim<VAR, 0>::value;
-  constexpr bool kObsWave = KW == 1 && VAR == VAR_V2;              // launched with 192 threads then, else with 128
+  constexpr bool kObsWave = KW == 1 && VAR == VAR_V2;              // launched with 256 threads then, else with 128
   const Head hd{blob, tile_bytes, n_envs};
   const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging | [12][64] reset words
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging | [12][64] reset words (or flag words + reset positions)
   const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);   // 0 main, 1 reset-RNG words, 2 observation
+  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);   // 0 main, 1 reset, 2 observation, 3 Monitor
   const int i = blockIdx.x * 64 + lane;
   const bool active = i < hd.n;
   char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
   uint32_t* words = reinterpret_cast<uint32_t*>(lds + 64 * OD);
   const int row0 = blockIdx.x * 64;
-  if (role == 1) {
-    const int32_t episode = iptr4(tile, lane)->w;
-    uint32_t r[12];
-    reset_words_serial(C, C.gid0 + i, episode, r);
-#pragma unroll
-    for (int k = 0; k < 12; k++) words[k * 64 + lane] = r[k];
-    __syncthreads();   // words published (pairs with the barrier in step_lane)
-    __syncthreads();   // pairs with the main wave's last barrier
-    return;
-  }
-  const int K = KW == 1 ? 1 : P.K;
-  Env<T, KW> e;
-  load_env<T, KW, 0>(K, tile, lane, e);
-  float act[kActDim];
-  const float4 a = io.actions[min(i, hd.n - 1)];
-  act[0] = a.x; act[1] = a.y; act[2] = a.z; act[3] = a.w;
+  const ArmArg<T, 0> AA{0};
   if constexpr (kObsWave) {
+    static_assert(OD % 4 == 0, "observation rows are written as float4");
+#ifdef AMENV_STAMPS   // diagnostic build: stamps of all four waves of the first 16 tiles (wave slot = 4 * tile + role)
+    unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamps_out = [&]() {
+      AMENV_STAMP_DRAIN();
+      AMENV_STAMP(6);
+      const int w = int(blockIdx.x) * 4 + role;
+      if (lane == 0 && w < kStampWaves)
+        for (int k = 0; k < kStampSlots; k++) io.stats[kStampBase + w * kStampSlots + k] = stamps_[k];
+    };
+#endif
+    AMENV_STAMP(0);
+    // [64] bit 0: episode ended on a real env, bit 1: the lane is reset | [64] info bits | [64] length | [64] return | [4][64] reset position, final yaw
+    uint32_t* flag = words;
+    float* rst = reinterpret_cast<float*>(words + 256);
+    if (role == 3) {                 // Monitor wave: owns totals replica [tile] during this launch -- loads it now, no atomics later
+      unsigned long long* totals = io.stats + size_t(blockIdx.x & (kStatsReplicas - 1)) * kStatsStride;
+      unsigned long long* acc = reinterpret_cast<unsigned long long*>(words + 512);   // [S_COUNT] this launch's additions (LDS)
+      unsigned long long mine = 0ull;
+      if (lane < S_COUNT) { mine = totals[lane]; acc[lane] = 0ull; }
+      AMENV_STAMP(1); AMENV_STAMP(2); AMENV_STAMP(3);
+      __syncthreads();
+      AMENV_STAMP(4);
+      const bool ended = (flag[lane] & 1u) != 0;
+      if (__ballot(ended) != 0ull) {   // wave-uniform
+        if (ended) {
+          const uint32_t bits = flag[64 + lane];
+          const int ep_len = int(flag[128 + lane]);
+          const float ep_ret = __uint_as_float(flag[192 + lane]);
+          accumulate_stats_lane(acc, 0, bits, ep_len, ep_ret);   // LDS adds (integers: the order does not matter)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < S_COUNT) totals[lane] = mine + acc[lane];
+      }
+      AMENV_STAMP(5);
+#ifdef AMENV_STAMPS
+      stamps_out();
+#endif
+      return;
+    }
+    if (role == 1) {
+      Env<T, KW> er;
+      er.episode = iptr4(tile, lane)->w;
+      uint32_t r[12];
+      reset_words_serial(C, C.gid0 + i, er.episode, r);
+      AMENV_STAMP(1);
+      reset_from_words<T, KW>(C, 1, er, r);
+      float ro[kObsDimMax];
+      observe_reset<T, KW, false, 0>(er, false, ro);
+      rst[lane] = float(er.px); rst[64 + lane] = float(er.py); rst[128 + lane] = float(er.pz); rst[192 + lane] = float(er.final_yaw);
+      AMENV_STAMP(2); AMENV_STAMP(3);
+      __syncthreads();               // flags published (and this wave's reset positions)
+      AMENV_STAMP(4);
+      if (flag[lane] & 2u) {         // (padding lanes run real arithmetic on their own slots: their state is reset too, rows are not written)
+        store_env_episode<T, KW>(1, tile, lane, er);
+        if (active) {
+          float4* d = reinterpret_cast<float4*>(io.obs + size_t(i) * OD);
+#pragma unroll
+          for (int j = 0; j < OD / 4; j++) d[j] = make_float4(ro[4 * j], ro[4 * j + 1], ro[4 * j + 2], ro[4 * j + 3]);
+        }
+      }
+      AMENV_STAMP(5);
+#ifdef AMENV_STAMPS
+      stamps_out();
+#endif
+      return;
+    }
+    Env<T, KW> e;
+    load_env<T, KW, 0>(1, tile, lane, e);
+    float act[kActDim];
+    const float4 a = io.actions[min(i, hd.n - 1)];
+    act[0] = a.x; act[1] = a.y; act[2] = a.z; act[3] = a.w;
     if (role == 2) {
+#ifdef AMENV_STAMPS
+      AMENV_STAMP_DRAIN();
+#endif
+      AMENV_STAMP(1);
       dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]);
+      AMENV_STAMP(2);
       float ho[kObsDimMax];
       observe<T, KW>(1, e, ho);
       stage_obs<OD>(lds + lane * OD, ho);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
-      __syncthreads();   // (words barrier: this wave only passes through)
-      __syncthreads();   // rows stored and acknowledged before the main wave may overwrite the rows of reset lanes
+      AMENV_STAMP(3);
+      __syncthreads();               // rows stored and acknowledged (wave 1 may now overwrite those of reset lanes); flags published
+      AMENV_STAMP(4);
+      if (flag[lane] & 1u) {
+        if (io.terminal_obs) {
+          float4* t = reinterpret_cast<float4*>(io.terminal_obs + size_t(i) * OD);
+#pragma unroll
+          for (int j = 0; j < OD / 4; j++) t[j] = make_float4(ho[4 * j], ho[4 * j + 1], ho[4 * j + 2], ho[4 * j + 3]);
+        }
+        if (io.ep_return) io.ep_return[i] = __uint_as_float(flag[192 + lane]);
+        if (io.ep_len) io.ep_len[i] = int(flag[128 + lane]);
+      }
+      AMENV_STAMP(5);
+#ifdef AMENV_STAMPS
+      stamps_out();
+#endif
       return;
     }
-  }
-  const LdsXchg x{lds, lane, words};
-  T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
-  const ArmArg<T, 0> AA{0};
-  constexpr int MAIN_ROLE = kObsWave ? ARM_ROLE_MAIN : ARM_ROLE_WORDS;
-  uint32_t bits = step_lane<T, NROT, KW, VAR, 0, MAIN_ROLE, LdsXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len,
-                                                                      ep_ret, x);
-  const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
-  accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
-  store_env_step<T, KW>(tile, lane, e);
-  if (was_reset) store_env_episode<T, KW>(K, tile, lane, e);
-  if (active) {
-    reinterpret_cast<T*>(io.reward)[i] = reward;
-    io.done[i] = is_done ? 1 : 0;
-    io.info[i] = bits;
-  }
-  if constexpr (kObsWave) {
-    __syncthreads();     // the observation wave's rows have landed
-    if (is_done && io.terminal_obs) {   // terminal observation = the pre-reset row staged by the observation wave
-      float* t = io.terminal_obs + size_t(i) * OD;
-#pragma unroll
-      for (int j = 0; j < OD; j++) t[j] = lds[lane * OD + j];
+#ifdef AMENV_STAMPS
+    AMENV_STAMP_DRAIN();
+#endif
+    AMENV_STAMP(1);
+    T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
+    uint32_t bits = step_lane<T, NROT, KW, VAR, 0, ARM_ROLE_FLAGS>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len, ep_ret);
+    AMENV_STAMP(2);
+    const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+    flag[lane] = (is_done ? 1u : 0u) | (was_reset ? 2u : 0u);
+    if (is_done) { flag[64 + lane] = bits; flag[128 + lane] = uint32_t(ep_len); flag[192 + lane] = __float_as_uint(ep_ret); }
+    AMENV_STAMP(3);
+    __syncthreads();
+    AMENV_STAMP(4);
+    if (was_reset) {                 // the rest of reset_from_words' result is constant: at rest, level, counters cleared
+      e.px = T(rst[lane]); e.py = T(rst[64 + lane]); e.pz = T(rst[128 + lane]); e.final_yaw = T(rst[192 + lane]);
+      e.vx = e.vy = e.vz = T(0); e.qw = T(1); e.qx = e.qy = e.qz = T(0); e.wx = e.wy = e.wz = T(0);
+      e.last_distance = T(-1); e.ep_return = T(0);
+      e.step = 0; e.counter = 0; e.flags = 0; e.episode += 1;
     }
-    if (was_reset && active) {
-      float* d = io.obs + size_t(i) * OD;
-#pragma unroll
-      for (int j = 0; j < OD; j++) d[j] = o[j];
+    store_env_step<T, KW>(tile, lane, e);
+    if (active) {
+      reinterpret_cast<T*>(io.reward)[i] = reward;
+      io.done[i] = is_done ? 1 : 0;
+      io.info[i] = bits;
     }
+    AMENV_STAMP(5);
+#ifdef AMENV_STAMPS
+    stamps_[7] = __ballot(is_done) != 0ull ? 1ull : 0ull;   // did this tile see an episode end?
+    stamps_out();
+#endif
   } else {
+    if (role == 1) {
+      const int32_t episode = iptr4(tile, lane)->w;
+      uint32_t r[12];
+      reset_words_serial(C, C.gid0 + i, episode, r);
+#pragma unroll
+      for (int k = 0; k < 12; k++) words[k * 64 + lane] = r[k];
+      __syncthreads();   // words published (pairs with the barrier in step_lane)
+      __syncthreads();   // pairs with the main wave's last barrier
+      return;
+    }
+    const int K = KW == 1 ? 1 : P.K;
+    Env<T, KW> e;
+    load_env<T, KW, 0>(K, tile, lane, e);
+    float act[kActDim];
+    const float4 a = io.actions[min(i, hd.n - 1)];
+    act[0] = a.x; act[1] = a.y; act[2] = a.z; act[3] = a.w;
+    const LdsXchg x{lds, lane, words};
+    T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
+    uint32_t bits = step_lane<T, NROT, KW, VAR, 0, ARM_ROLE_WORDS, LdsXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset, ep_len,
+                                                                           ep_ret, x);
+    const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+    accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
+    store_env_step<T, KW>(tile, lane, e);
+    if (was_reset) store_env_episode<T, KW>(K, tile, lane, e);
+    if (active) {
+      reinterpret_cast<T*>(io.reward)[i] = reward;
+      io.done[i] = is_done ? 1 : 0;
+      io.info[i] = bits;
+    }
     stage_obs<OD>(lds + lane * OD, o);
     __syncthreads();
     flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);

@@ -46,6 +46,8 @@ s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for bs in (64, 256):
     print(f"noop  chain, block {bs:3d}: {chain(lambda t: lib.amenv_debug_noop(env._h, 0, bs, s())):.3f} us/kernel")
     print(f"touch chain, block {bs:3d}: {chain(lambda t: lib.amenv_debug_noop(env._h, 1, bs, s())):.3f} us/kernel")
+for grid, bs in ((256, 64), (1024, 64), (4096, 64), (256, 256), (1024, 256)):   # explicit grids: how the floor depends on the number of workgroups
+    print(f"noop  chain, grid {grid:4d} x {bs:3d}: {chain(lambda t: lib.amenv_debug_noop(env._h, grid, bs, s())):.3f} us/kernel")
 print(f"step  chain            : {chain(lambda t: env.step(ring[t])):.3f} us/kernel")
 # eager (no graph) back-to-back
 for name, fn in (("noop", lambda t: lib.amenv_debug_noop(env._h, 0, 64, s())), ("step", lambda t: env.step(ring[t % 64]))):
