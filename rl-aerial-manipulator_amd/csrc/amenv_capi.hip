@@ -360,17 +360,17 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
   if constexpr (NJ == 3 && sizeof(T) == 4) {
-    if (e.team) {    // 16 lanes per env, 4 envs per one-wave workgroup
-      const dim3 g2(e.n_tiles * 16), b2(64);
+    if (e.team) {    // 16 lanes per env, 4 envs per workgroup (step: main wave + episode-end helper wave; rollout: one wave)
+      const dim3 g2(e.n_tiles * 16), b2(64), b2s(128);
       const TeamParams TP = make_team(e);
       const float* act = reinterpret_cast<const float*>(io.actions);
       if (T_steps > 0) {
         hipLaunchKernelGGL((rollout_kernel_team<NROT>), g2, b2, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, T_steps, tl, C, TP);
         return hipGetLastError();
       }
-      if (timed) hipExtLaunchKernelGGL((step_kernel_team<NROT>), g2, b2, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done,
+      if (timed) hipExtLaunchKernelGGL((step_kernel_team<NROT>), g2, b2s, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done,
                                        io.info, tl, C, TP);
-      else hipLaunchKernelGGL((step_kernel_team<NROT>), g2, b2, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, tl, C, TP);
+      else hipLaunchKernelGGL((step_kernel_team<NROT>), g2, b2s, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, tl, C, TP);
       return hipGetLastError();
     }
     if (T_steps == 0 && e.arm2w) {   // one tile per 128-thread workgroup: main + helper wave
@@ -622,7 +622,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                               cfg->dtype == AMENV_F64 ? "double" : "float",
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
-  else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6,v2+arm3> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave)");
+  else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6,v2+arm3> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave + episode-end helper wave)");
   else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,

@@ -314,9 +314,55 @@ __device__ __forceinline__ void team_store(char* tile, int i, const TeamLane& L,
 
 struct TeamOut { float reward; uint32_t bits; float vA, vB, vC; bool ended; int ep_len; float ep_ret; };
 
+// What a reset leaves in this lane's registers: position / waypoint component, final yaw, and the three observation values of the reset
+// state (at rest, level, arm at home).  Lane c < 3 of every quad computes Philox block c; the 12 words are then broadcast inside the quad.
+// Pure function of (seed, global env id, episode): the step kernel's helper wave evaluates it for every row while the main wave integrates.
+struct TeamReset { float P, WP, final_yaw, vA, vB, vC; };
+__device__ __forceinline__ TeamReset team_reset(const TeamParams& P, const ColdParams& C, const TeamLane& L, int32_t episode, int i) {
+  const float* c = L.c;
+  uint32_t wds[4];
+  const int64_t gid = C.gid0 + i;
+  philox4x32_10(C.seed_lo, C.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(episode), uint32_t(L.cc), wds);
+  uint32_t r[12];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    r[k] = uint32_t(qpi<0, 0, 0, 0>(int(wds[k]))); r[4 + k] = uint32_t(qpi<1, 1, 1, 1>(int(wds[k]))); r[8 + k] = uint32_t(qpi<2, 2, 2, 2>(int(wds[k])));
+  }
+  Env<float, 1> e;
+  e.episode = episode;
+  reset_from_words<float, 1>(C, 1, e, r);
+  const float e0 = c[TC_E0], e1 = c[TC_E1], e2 = c[TC_E2];
+  TeamReset R;
+  R.P = fma_(e0, e.px, fma_(e1, e.py, e2 * e.pz));
+  R.WP = fma_(e0, e.wp[0][0], fma_(e1, e.wp[0][1], e2 * e.wp[0][2]));
+  R.final_yaw = e.final_yaw;
+  const float eo = fma_(e0, P.ee_home[0], fma_(e1, P.ee_home[1], e2 * P.ee_home[2]));
+  const float zero = 0.0f, Q = L.cc == 0 ? 1.0f : 0.0f;
+  R.vA = (L.q0 ? R.P : (L.q1 ? zero : (L.q2 ? Q : zero))) * c[TC_OBS_A];
+  const float tp = P.ee_task != 0 ? R.P + eo : R.P;
+  R.vB = (L.q0 ? R.WP - tp : (L.q1 ? 0.0f : (L.q2 ? R.final_yaw : zero))) * c[TC_OBS_B];
+  R.vC = (L.q0 ? zero : eo) * c[TC_OBS_C];
+  return R;
+}
+
 // One control step of one env row, state in registers: mixer -> RK4 -> forward kinematics -> task step -> (episode end: Monitor outputs,
 // reset) -> observation values.  act: wrench action a0..a3 (one per lane), actj: joint commands (joint per lane).
-template <int NROT>
+// A reset row's registers from team_reset's values; the rest of WaypointQuadEnv.reset's result is constant (at rest, level, arm at home,
+// counters cleared, episode + 1).  `e`: the scalar copies team_advance writes back into E afterwards.
+__device__ __forceinline__ void team_apply_reset(const TeamLane& L, const TeamReset& R, TeamEnv& E, Env<float, 1>& e, TeamOut& o) {
+  TeamState& y = E.y;
+  y.P = R.P; y.V = 0.0f; y.W = 0.0f; y.TH = 0.0f; y.THD = 0.0f;
+  y.Q = L.cc == 0 ? 1.0f : 0.0f;
+  E.WP = R.WP; E.final_yaw = R.final_yaw;
+  e.last_distance = -1.0f; e.ep_return = 0.0f;
+  e.step = 0; e.counter = 0; e.flags = 0; e.episode += 1;
+  o.vA = R.vA; o.vB = R.vB; o.vC = R.vC;
+  o.bits |= AMENV_INFO_WAS_RESET;
+}
+
+// HELPED: the caller's helper wave does the episode-end work (step kernel); this function then stops after the task step and the
+// observation values, with o.ended / o.ep_len / o.ep_ret set.
+template <int NROT, bool HELPED = false>
 __device__ __forceinline__ TeamOut team_advance(const TeamParams& P, const ColdParams& C, const TeamLane& L, TeamEnv& E, float act, float actj, int i, bool active,
                                                 float* terminal_obs, float* ep_return_out, int32_t* ep_len_out) {
   constexpr int OD = 29;
@@ -388,38 +434,23 @@ __device__ __forceinline__ TeamOut team_advance(const TeamParams& P, const ColdP
   o.ep_len = 0; o.ep_ret = 0.0f;
   if (o.ended) {   // uniform within the row; SB3 DummyVecEnv + Monitor contract
     o.ep_len = e.step; o.ep_ret = e.ep_return;
-    if (active) {
-      if (terminal_obs) {
-        const uint32_t row = uint32_t(i) * OD;
-        if (L.okA) terminal_obs[row + L.offA] = o.vA;
-        if (L.okB) terminal_obs[row + L.offB] = o.vB;
-        if (L.okC) terminal_obs[row + L.offC] = o.vC;
+    if constexpr (!HELPED) {
+      if (active) {
+        if (terminal_obs) {
+          const uint32_t row = uint32_t(i) * OD;
+          if (L.okA) terminal_obs[row + L.offA] = o.vA;
+          if (L.okB) terminal_obs[row + L.offB] = o.vB;
+          if (L.okC) terminal_obs[row + L.offC] = o.vC;
+        }
+        if (L.lead) {
+          if (ep_return_out) ep_return_out[i] = o.ep_ret;
+          if (ep_len_out) ep_len_out[i] = o.ep_len;
+        }
       }
-      if (L.lead) {
-        if (ep_return_out) ep_return_out[i] = o.ep_ret;
-        if (ep_len_out) ep_len_out[i] = o.ep_len;
+      if (resets) {
+        const TeamReset R = team_reset(P, C, L, e.episode, i);
+        team_apply_reset(L, R, E, e, o);
       }
-    }
-    if (resets) {
-      // reset RNG: lane c < 3 of every quad computes Philox block c; the 12 words are then broadcast inside the quad
-      uint32_t wds[4];
-      const int64_t gid = C.gid0 + i;
-      philox4x32_10(C.seed_lo, C.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(e.episode), uint32_t(L.cc), wds);
-      uint32_t r[12];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        r[k] = uint32_t(qpi<0, 0, 0, 0>(int(wds[k]))); r[4 + k] = uint32_t(qpi<1, 1, 1, 1>(int(wds[k]))); r[8 + k] = uint32_t(qpi<2, 2, 2, 2>(int(wds[k])));
-      }
-      reset_from_words<float, 1>(C, 1, e, r);
-      e.eox = P.ee_home[0]; e.eoy = P.ee_home[1]; e.eoz = P.ee_home[2];
-      const float e0 = c[TC_E0], e1 = c[TC_E1], e2 = c[TC_E2];
-      y.P = fma_(e0, e.px, fma_(e1, e.py, e2 * e.pz));
-      y.V = 0.0f; y.W = 0.0f; y.TH = 0.0f; y.THD = 0.0f;
-      y.Q = L.cc == 0 ? 1.0f : 0.0f;
-      E.WP = fma_(e0, e.wp[0][0], fma_(e1, e.wp[0][1], e2 * e.wp[0][2]));
-      E.final_yaw = e.final_yaw;
-      obs_vals(y, E.WP, fma_(e0, e.eox, fma_(e1, e.eoy, e2 * e.eoz)), E.final_yaw);
-      o.bits |= AMENV_INFO_WAS_RESET;
     }
   }
   E.last_distance = e.last_distance; E.ep_return = e.ep_return;
@@ -443,23 +474,64 @@ __device__ __forceinline__ void team_store_outputs(const TeamLane& L, const Team
   }
 }
 
-// One control step of 4 envs per wavefront.  grid = n_tiles * 16 workgroups of 64 threads.
+// One control step of 4 envs per main wavefront.  grid = n_tiles * 16 workgroups of 128 threads: wave 0 integrates, wave 1 helps with
+// episode ends.  At 4096 envs ~10 of the 1024 main waves see an episode end in every launch, the launch is as slow as its slowest wave,
+// and episode-end code (rarely run on any one CU) costs ~7 clocks per instruction: with everything inline those waves ran 2,100 clocks
+// (0.9 us of 5.8) longer than the rest (tools/stamp_team.py).  So the helper wave evaluates team_reset for all four rows while the main
+// wave integrates, leaves the values in LDS and loads the workgroup's replica of the Monitor totals; after the kernel's ONE barrier the
+// main wave's episode-end path is six LDS reads (+ three terminal-observation stores after its regular stores), and the helper writes
+// Monitor's return / length and adds the ended episodes to its replica (owned for the launch when the grid has at most kStatsReplicas
+// workgroups: plain read-modify-write; otherwise atomics).
 template <int NROT>
-__global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float* __restrict__ actions,
-                                                       float* __restrict__ obs, float* __restrict__ reward_out, uint8_t* __restrict__ done,
-                                                       uint32_t* __restrict__ info, const StepTail tl, const ColdParams C, const TeamParams P) {
+__global__ __launch_bounds__(128) void step_kernel_team(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float* __restrict__ actions,
+                                                        float* __restrict__ obs, float* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                        uint32_t* __restrict__ info, const StepTail tl, const ColdParams C, const TeamParams P) {
   static_assert(NROT == 6, "team kernel: 6-rotor airframe");
-  constexpr int AD = 7;
+  constexpr int AD = 7, OD = 29;
+  __shared__ float rst[6][64];                     // team_reset's values, lane for lane
+  __shared__ uint32_t fl[4][4];                    // per row: bit 0 ended on a real env, bit 1 reset | info bits | length | return
+  __shared__ unsigned long long acc[S_COUNT];      // this launch's additions to the Monitor totals
 #ifdef AMENV_STAMPS
   unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  AMENV_STAMP(0);
+  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
   TeamLane L;
   L.init(P);
-  const int i = team_group_of_block(int(blockIdx.x), int(gridDim.x)) * 4 + (L.lane >> 4);   // env of this row
+  const int row = L.lane >> 4;
+  const int i = team_group_of_block(int(blockIdx.x), int(gridDim.x)) * 4 + row;   // env of this row
   const bool active = i < n_envs;
-  const int ia = active ? i : n_envs - 1;                   // rows past the end redo the last env's arithmetic (their outputs are masked)
   char* tile = static_cast<char*>(blob) + size_t(i >> 6) * tile_bytes;
+  if (role == 1) {
+    const bool owned = gridDim.x <= kStatsReplicas;   // wave-uniform
+    unsigned long long* totals = tl.stats + size_t(blockIdx.x & (kStatsReplicas - 1)) * kStatsStride;
+    unsigned long long mine = 0ull;
+    if (L.lane < S_COUNT) { if (owned) mine = totals[L.lane]; acc[L.lane] = 0ull; }
+    const int32_t episode = (reinterpret_cast<const int4*>(tile) + (i & 63))->w;
+    const TeamReset R = team_reset(P, C, L, episode, i);
+    rst[0][L.lane] = R.P; rst[1][L.lane] = R.WP; rst[2][L.lane] = R.final_yaw;
+    rst[3][L.lane] = R.vA; rst[4][L.lane] = R.vB; rst[5][L.lane] = R.vC;
+    __syncthreads();
+    const bool ended = (fl[row][0] & 1u) != 0 && L.lead;   // one lane per ended row
+    if (__ballot(ended) != 0ull) {   // wave-uniform
+      if (ended) {
+        const uint32_t bits = fl[row][1];
+        const int ep_len = int(fl[row][2]);
+        const float ep_ret = __uint_as_float(fl[row][3]);
+        if (tl.ep_return) tl.ep_return[i] = ep_ret;
+        if (tl.ep_len) tl.ep_len[i] = ep_len;
+        if (owned) accumulate_stats_lane(acc, 0, bits, ep_len, ep_ret);               // LDS adds
+        else accumulate_stats_lane(tl.stats, int(blockIdx.x), bits, ep_len, ep_ret);  // global atomics
+      }
+      if (owned) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (L.lane < S_COUNT) totals[L.lane] = mine + acc[L.lane];
+      }
+    }
+    return;
+  }
+  AMENV_STAMP(0);
+  const int ia = active ? i : n_envs - 1;                   // rows past the end redo the last env's arithmetic (their outputs are masked)
   TeamEnv E;
   team_load(tile, i, L, E);
   const float act = actions[size_t(ia) * AD + L.cc];                                     // a0..a3: one per lane
@@ -467,13 +539,35 @@ __global__ __launch_bounds__(64) void step_kernel_team(void* __restrict__ blob, 
   AMENV_STAMP(1);          // loads issued
   AMENV_STAMP_DRAIN();
   AMENV_STAMP(2);          // loads landed
-  AMENV_STAMP(3);
-  const TeamOut o = team_advance<NROT>(P, C, L, E, act, actj, i, active, tl.terminal_obs, tl.ep_return, tl.ep_len);
-  AMENV_STAMP(4);          // mixer + RK4 + forward kinematics + task step + episode end / reset
-  accumulate_stats(tl.stats, int(blockIdx.x), o.bits, active && o.ended && L.lead, o.ep_len, o.ep_ret);
-  AMENV_STAMP(5);          // Monitor totals
+  TeamOut o = team_advance<NROT, true>(P, C, L, E, act, actj, i, active, nullptr, nullptr, nullptr);
+  const bool resets = o.ended && (P.flags & AMENV_FLAG_AUTO_RESET);
+  if (L.lead) {
+    fl[row][0] = (o.ended && active ? 1u : 0u) | (resets ? 2u : 0u);
+    if (o.ended) { fl[row][1] = o.bits; fl[row][2] = uint32_t(o.ep_len); fl[row][3] = __float_as_uint(o.ep_ret); }
+  }
+  AMENV_STAMP(4);          // mixer + RK4 + forward kinematics + task step
+#ifdef AMENV_STAMPS
+  stamps_[3] = __ballot(o.ended && active) != 0ull ? 1ull : 0ull;   // (not a time) did one of this wave's envs end its episode?
+#endif
+  __syncthreads();
+  const float tA = o.vA, tB = o.vB, tC = o.vC;              // the terminal observation of a row that ended
+  if (resets) {
+    const TeamReset R{rst[0][L.lane], rst[1][L.lane], rst[2][L.lane], rst[3][L.lane], rst[4][L.lane], rst[5][L.lane]};
+    Env<float, 1> e;
+    e.episode = E.episode;
+    team_apply_reset(L, R, E, e, o);
+    E.last_distance = e.last_distance; E.ep_return = e.ep_return;
+    E.step = e.step; E.counter = e.counter; E.flags = e.flags; E.episode = e.episode;
+  }
+  AMENV_STAMP(5);          // barrier + reset values
   team_store(tile, i, L, E);
   team_store_outputs<false>(L, o, uint32_t(i), active, obs, reward_out, done, info);
+  if (o.ended && active && tl.terminal_obs) {
+    const uint32_t r0 = uint32_t(i) * OD;
+    if (L.okA) tl.terminal_obs[r0 + L.offA] = tA;
+    if (L.okB) tl.terminal_obs[r0 + L.offB] = tB;
+    if (L.okC) tl.terminal_obs[r0 + L.offC] = tC;
+  }
   AMENV_STAMP(6);          // stores issued
 #ifdef AMENV_STAMPS
   AMENV_STAMP_DRAIN();
