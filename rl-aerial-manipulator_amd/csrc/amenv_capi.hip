@@ -593,7 +593,8 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                 "and at most 65536 envs (its Monitor wave owns one of the 1024 replicas of the running totals per tile)");
   }
   // lane-team kernel (16 lanes per env): one wavefront per SIMD up to 4096 envs; measured against the two-wave kernel on MI355X:
-  // 5.9 vs 7.7 us at 2048 envs, 6.1 vs 7.8 at 4096, 9.0 vs 7.9 at 8192 (two team wavefronts per SIMD) -> AUTO up to 6144 envs
+  // 4.9 vs 7.5 us at 2048 envs, 5.1 vs 7.6 at 4096, 7.5 vs 7.7 at 6144, 11.4 vs 7.8 at 8192 (a team workgroup is a main wave + an
+  // episode-end helper wave: above 4096 envs the SIMDs hold more than two waves) -> AUTO up to 6144 envs
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes)
     e->team = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 6144 : want == AMENV_KERNEL_TEAM;
   if (want == AMENV_KERNEL_TEAM && !e->team) {

@@ -2,11 +2,6 @@
 R=$PWD; O=$R/gpurun_out/r02g; mkdir -p $O
 python tools/vecenv_rate.py --vehicle quad > $O/vecenv_quad.json 2>/dev/null; cat $O/vecenv_quad.json
 python tools/vecenv_rate.py --vehicle hexa_arm > $O/vecenv_arm.json 2>/dev/null; cat $O/vecenv_arm.json
-python tools/ppo_bench.py --vehicle quad > $O/ppo_quad.json 2>/dev/null; python -c "import json; d=json.load(open('$O/ppo_quad.json')); print({k:d[k] for k in d if k in ('value','rollout_s','update_s','rollout_env_steps_per_s')} or d)"
-python tools/ppo_bench.py --vehicle hexa_arm > $O/ppo_arm.json 2>/dev/null; python -c "import json; d=json.load(open('$O/ppo_arm.json')); print(json.dumps(d)[:600])"
-python tools/ppo_bench.py --vehicle hexa_arm --fused-rollout > $O/ppo_arm_fused.json 2>/dev/null; python -c "import json; d=json.load(open('$O/ppo_arm_fused.json')); print(json.dumps(d)[:600])"
-python tools/ppo_bench.py --vehicle hexa_arm --fused-rollout --envs 4096 --n-steps 256 > $O/ppo_arm_fused_4096.json 2>/dev/null; python -c "import json; d=json.load(open('$O/ppo_arm_fused_4096.json')); print(json.dumps(d)[:600])"
-python tools/ppo_bench.py --vehicle hexa_arm --envs 4096 --n-steps 256 > $O/ppo_arm_4096.json 2>/dev/null; python -c "import json; d=json.load(open('$O/ppo_arm_4096.json')); print(json.dumps(d)[:600])"
 for V in hexa quad; do python bench.py --vehicle $V --no-cpu-baseline --no-extras > $O/bench_$V.json 2>/dev/null; python -c "
 import json
 d=json.load(open('$O/bench_$V.json')); print('$V dev us/step %.3f  %.4g env-steps/s  %s' % (d['device_ms_per_step']*1e3, d['value'], d['config']['kernel'][:40]))"; done

@@ -8,7 +8,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int CHAINS, int VALU, int LOADS>
-__global__ __launch_bounds__(256) void k(const float* __restrict__ w, float* out, unsigned long long* clk, int iters) {
+__global__ __launch_bounds__(512) void k(const float* __restrict__ w, float* out, unsigned long long* clk, int iters) {
   f32x16 acc[CHAINS];
   for (int c = 0; c < CHAINS; c++) for (int r = 0; r < 16; r++) acc[c][r] = 0.0f;
   float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f, x = a;
