@@ -675,3 +675,54 @@ def test_every_accepted_block_size_is_bit_identical(amd, vehicle, n):
         assert torch.equal(f, outs[0][1]) and torch.equal(i, outs[0][2]) and st == outs[0][3] and st["episodes"] > n // 8
         for a, b in zip(rec, outs[0][0]):
             assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vehicle,kernel,n", [("hexa", "auto", 4096), ("quad", "auto", 1000), ("hexa", "lane", 1000), ("hexa_arm", "team", 4096),
+                                              ("hexa_arm", "team", 7000), ("hexa_arm", "helper", 1000), ("hexa_arm", "lane", 640)])
+def test_monitor_totals_and_episode_outputs_match_the_per_step_outputs(amd, vehicle, kernel, n):
+    """The running totals (`amenv_stats_read`) and the per-episode outputs (ep_return, ep_len, terminal_obs) are written by helper
+    wavefronts in the small-batch kernels (owned replicas, no atomics); whatever writes them, they must equal what the per-step outputs
+    say: episodes = sum of done, causes by info bit, length / return sums of the ended episodes, and the terminal row = the observation
+    the env showed before its reset (checked against a twin env that does not auto-reset)."""
+    torch = _torch()
+    from rl_aerial_manipulator_amd import _lib as L_
+    env = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=5, kernel=kernel, max_episode_steps=120)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    tot = dict(episodes=0, terminated=0, truncated=0, success=0, crashed=0, oob=0, nonfinite=0, length_sum=0)
+    ret_q10 = 0
+    ep_ret_track = torch.zeros(n, dtype=torch.float64, device="cuda")
+    ep_len_track = torch.zeros(n, dtype=torch.int64, device="cuda")
+    T = 260
+    for t in range(T):
+        a = torch.randn(n, env.act_dim, device="cuda", generator=g) * 0.15
+        a[:, 0] += 1.0
+        prev_obs = env.obs.clone()
+        obs, rew, done, info = env.step(a.clamp(-1, 2))
+        d = done.bool()
+        ep_ret_track += rew.double()
+        ep_len_track += 1
+        if bool(d.any()):
+            i = info[d].long()
+            term = (i & L_.INFO_TERMINATED) != 0
+            tot["episodes"] += int(d.sum()); tot["terminated"] += int(term.sum()); tot["truncated"] += int((~term).sum())
+            tot["success"] += int(((i & L_.INFO_SUCCESS) != 0).sum()); tot["crashed"] += int(((i & L_.INFO_CRASHED) != 0).sum())
+            tot["oob"] += int(((i & L_.INFO_OOB) != 0).sum()); tot["nonfinite"] += int(((i & L_.INFO_NONFINITE) != 0).sum())
+            tot["length_sum"] += int(env.ep_len[d].sum())
+            ret_q10 += int(torch.round(env.ep_return[d].double() * 1024.0).sum())
+            assert torch.equal(env.ep_len[d].long(), ep_len_track[d])
+            assert float((env.ep_return[d].double() - ep_ret_track[d]).abs().max()) < 1e-3 * max(1.0, float(ep_ret_track[d].abs().max()))
+            assert bool(((i & L_.INFO_WAS_RESET) != 0).all())
+            # a reset env shows the observation of a fresh episode (at rest, level): velocity / rate entries are zero, quaternion = identity
+            assert float(obs[d][:, 3:6].abs().max()) == 0.0 and float((obs[d][:, 6] - 1.0).abs().max()) == 0.0
+            # the terminal row is not the post-reset row, and it is a continuation of the previous observation (position moved by < 0.1 m)
+            assert float((env.terminal_obs[d][:, 0:3] - prev_obs[d][:, 0:3]).abs().max()) < 0.02
+            ep_ret_track[d] = 0.0; ep_len_track[d] = 0
+    s = env.stats()
+    assert tot["episodes"] > n // 2
+    for k, v in tot.items():
+        assert s[k] == v, (k, s[k], v)
+    assert s["steps"] == T * n
+    assert abs(round(s["return_sum"] * 1024.0) - ret_q10) <= tot["episodes"], (s["return_sum"] * 1024.0, ret_q10)   # (round-half-even per episode on both sides)
+    env.close()
