@@ -119,14 +119,16 @@ class GpuVecEnv(_SB3VecEnv):
             obs, rew = self._to_numpy(obs), self._to_numpy(rew).astype(np.float32)
             done, bits = self._to_numpy(done).astype(bool), self._to_numpy(bits).view(np.uint32)
         else:
-            # numpy boundary through page-locked staging: one async H2D copy of the actions, the step launch, four async D2H copies,
-            # ONE stream synchronisation (pageable tensors made each of the five copies a blocking staged transfer)
+            # numpy boundary through page-locked staging: one async H2D copy of the actions, the step launch, six async D2H copies
+            # (Monitor's return / length ride along: 8 B per env, so that an episode end costs no synchronisation of its own),
+            # ONE stream synchronisation (pageable tensors made each of the copies a blocking staged transfer)
             P = self._pin
             np.copyto(P["act_np"], self._actions)
             P["act_dev"].copy_(P["act"], non_blocking=True)
             o, r, d, i = b.step(P["act_dev"])
             P["obs"].copy_(o, non_blocking=True); P["rew"].copy_(r, non_blocking=True)
             P["done"].copy_(d, non_blocking=True); P["bits"].copy_(i, non_blocking=True)
+            P["eret"].copy_(b.ep_return, non_blocking=True); P["elen"].copy_(b.ep_len, non_blocking=True)
             torch.cuda.current_stream(b.device).synchronize()
             # SB3 keeps `_last_obs` across the next step: hand out copies, never views of the staging buffers
             obs, rew = P["obs_np"].copy(), P["rew_np"].astype(np.float32)
@@ -135,9 +137,13 @@ class GpuVecEnv(_SB3VecEnv):
         ev = np.nonzero(bits & ~np.uint32(L.INFO_WAS_RESET))[0]
         if ev.size:
             dn = ev[done[ev]]
-            tobs = self._to_numpy(b.terminal_obs[dn]) if dn.size else None
-            eret = self._to_numpy(b.ep_return[dn]) if dn.size else None
-            elen = self._to_numpy(b.ep_len[dn]) if dn.size else None
+            if self._pin is not None:   # the terminal rows of the few envs that ended: one gathered copy; return / length are staged already
+                tobs = self._to_numpy(b.terminal_obs[torch.from_numpy(dn).to(b.device)]) if dn.size else None
+                eret, elen = self._pin["eret_np"][dn], self._pin["elen_np"][dn]
+            else:
+                tobs = self._to_numpy(b.terminal_obs[dn]) if dn.size else None
+                eret = self._to_numpy(b.ep_return[dn]) if dn.size else None
+                elen = self._to_numpy(b.ep_len[dn]) if dn.size else None
             pos = {int(i): k for k, i in enumerate(dn)}
             now = round(time.time() - self._t0, 6)
             for i in ev:
@@ -203,8 +209,9 @@ class GpuVecEnv(_SB3VecEnv):
         n, od, ad = backend.num_envs, backend.obs_dim, backend.act_dim
         P = {"act": torch.empty(n, ad, dtype=torch.float32).pin_memory(), "act_dev": torch.empty(n, ad, dtype=torch.float32, device=dev),
              "obs": torch.empty(n, od, dtype=torch.float32).pin_memory(), "rew": torch.empty(n, dtype=backend.reward.dtype).pin_memory(),
-             "done": torch.empty(n, dtype=torch.uint8).pin_memory(), "bits": torch.empty(n, dtype=torch.int32).pin_memory()}
-        for k in ("act", "obs", "rew", "done", "bits"):
+             "done": torch.empty(n, dtype=torch.uint8).pin_memory(), "bits": torch.empty(n, dtype=torch.int32).pin_memory(),
+             "eret": torch.empty(n, dtype=backend.ep_return.dtype).pin_memory(), "elen": torch.empty(n, dtype=backend.ep_len.dtype).pin_memory()}
+        for k in ("act", "obs", "rew", "done", "bits", "eret", "elen"):
             P[k + "_np"] = P[k].numpy()
         return P
 
