@@ -583,3 +583,32 @@ def test_ppo_update_fused_path_trains_like_the_torch_path():
     assert float((p0 - p1).abs().max()) < 0.05 * 8 * 2e-4, float((p0 - p1).abs().max())
     for k in o0:
         assert abs(o0[k] - o1[k]) <= 2e-3 * max(abs(o0[k]), 1e-3), (k, o0[k], o1[k])
+
+
+def test_fused_update_with_rccl_exchange_between_reduce_and_adam():
+    """The multi-GPU form of the fused update -- gradient reduce | RCCL all-reduce of the flat gradient | clip + Adam with the 1 / world
+    scale folded in -- on a 1-rank RCCL group (forced exchange): same parameters, bit for bit, as the update without a process group."""
+    import socket
+    import torch.distributed as dist
+    from rl_aerial_manipulator_amd.ppo import MinibatchStep, ppo_update
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        res = []
+        for with_dist in (False, True):
+            pol, data = _mlp_problem(29, 7, 16384)
+            opt = torch.optim.Adam([pol.flat_param.requires_grad_(True)], lr=2e-4, eps=1e-5, capturable=True)
+            pol.flat_param.grad = pol.flat_grad
+            step = MinibatchStep(pol, opt, dist=dist if with_dist else None, split_graphs=True if with_dist else None)
+            assert step.fused_mlp and step.fused_adam and not step.use_graph
+            gen = torch.Generator(device="cuda").manual_seed(11)
+            ppo_update(pol, opt, *data, batch_size=4096, n_epochs=2, generator=gen, step=step)
+            res.append(pol.flat_param.detach().clone())
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        assert torch.equal(res[0], res[1]) and float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
