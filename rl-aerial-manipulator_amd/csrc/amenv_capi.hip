@@ -17,6 +17,7 @@
 #include "amenv_kernels.hpp"
 #include "amenv_team.hpp"
 #include "amenv_team_policy.hpp"
+#include "amenv_lane_policy.hpp"
 #include "amenv_obsnorm.hpp"
 #include "amenv_policy.hpp"
 #include "amenv_train.hpp"
@@ -749,6 +750,22 @@ int amenv_rollout_policy(amenv* e, int32_t n_steps, const float* flat_params, ui
   io.seed_lo = uint32_t(seed); io.seed_hi = uint32_t(seed >> 32); io.draw0 = draw0;
   io.obs = obs; io.actions = actions; io.logp = logp; io.values = values; io.rewards = rewards; io.dones = dones; io.info = info_bits;
   io.terminal_obs = terminal_obs;
+  // The env part follows the step kernel's choice: 16 lanes per env where amenv_step runs the lane-team kernel (small batches), else one
+  // lane per env (amenv_lane_policy.hpp; 64 envs per workgroup up to 16384 envs, 128 above: one workgroup per CU either way).
+  if (!e->team) {
+    ArmArg<float, 3> AA;
+    AA.p = make_arm<float>(*e);
+    const HotParams<float, 6> HP = make_hot<float, 6>(*e);
+    if (e->cfg.num_envs <= 16384)
+      hipLaunchKernelGGL((rollout_policy_kernel_lane<6, 1>), dim3(e->n_tiles), dim3(320), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io, e->stats, HP,
+                         make_cold(*e), AA);
+    else
+      hipLaunchKernelGGL((rollout_policy_kernel_lane<6, 2>), dim3((e->n_tiles + 1) / 2), dim3(384), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io, e->stats,
+                         HP, make_cold(*e), AA);
+    AMENV_HIP(e, hipGetLastError());
+    e->steps += uint64_t(e->cfg.num_envs) * uint64_t(n_steps);
+    return AMENV_OK;
+  }
   const TeamParams TP = make_team(*e);
   // one 16-env workgroup per CU up to 4096 envs; above that two wavefronts per SIMD pay (measured on MI355X: 32768 envs)
   const char* occ_env = std::getenv("AMENV_POLICY_OCC");   // bench / A-B only (tools/): 1 or 2

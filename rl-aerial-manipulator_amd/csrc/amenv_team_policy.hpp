@@ -10,6 +10,7 @@
 //   * activations travel through LDS (bf16), 5 workgroup barriers per step; tanh = 1 - 2 / (exp(2x) + 1) on v_exp / v_rcp;
 //   * action noise: Philox4x32-10 keyed (seed, global env id, draw index, block) as amenv_gaussian_act, Box-Muller on the fast
 //     intrinsics (v_log / v_sin / v_cos): the same distribution, not the same bits as the one-launch-per-op path.
+// Above the lane-team kernel's batch range the same loop runs with one lane per env for the environment: amenv_lane_policy.hpp.
 // bf16 rounding of observations / activations / weights perturbs the action means by ~1e-2 of their scale: an opt-in ROLLOUT mode
 // (ppo.py fused_rollout=True); evaluate_policy / parity paths keep the fp32 kernels.
 #pragma once

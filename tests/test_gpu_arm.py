@@ -364,9 +364,10 @@ def test_team_rollout_kernel_equals_team_steps():
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("n", [300, 4096])
-def test_closed_loop_policy_rollout_kernel(n):
-    """amenv_rollout_policy: T closed-loop steps in one launch (bf16-MFMA actor / critic, Gaussian sampling, clip, team env step).
+@pytest.mark.parametrize("n,kernel", [(300, "team"), (4096, "team"), (1000, "lane"), (20000, "auto")])
+def test_closed_loop_policy_rollout_kernel(n, kernel):
+    """amenv_rollout_policy: T closed-loop steps in one launch (bf16-MFMA actor / critic, Gaussian sampling, clip, env step) in its two
+    forms: 16 lanes per env (where amenv_step runs the lane-team kernel) and one lane per env (64 or 128 envs per workgroup).
     The env part is checked EXACTLY by replaying the recorded (clipped) actions through amenv_step on a second env; the policy part against
     the fp32 torch modules on the recorded observations (bf16 tolerance: means / values within 3e-2 of their scale); the samples
     statistically (z = (a - mean) / std ~ N(0, 1), log-probs consistent with the samples)."""
@@ -379,8 +380,9 @@ def test_closed_loop_policy_rollout_kernel(n):
         pol.log_std.data.fill_(-1.2)
         for m in (pol.action_net,):                              # a less timid head than SB3's 0.01-gain init: means of O(0.3)
             m.weight.mul_(30.0)
-    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="team", max_episode_steps=60)
-    ref = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="team", max_episode_steps=60)
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel, max_episode_steps=60)
+    ref = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel, max_episode_steps=60)
+    assert ("team" in env.kernel_name) == (kernel == "team")
     o0 = env.reset().clone(); ref.reset()
     dev = env.device
     obs = torch.zeros(T + 1, n, 29, device=dev); acts = torch.zeros(T, n, 7, device=dev)
@@ -414,9 +416,40 @@ def test_closed_loop_policy_rollout_kernel(n):
     lp32 = (-0.5 * z * z - pol.log_std.detach() - 0.9189385332).sum(1)
     assert float((logp.reshape(-1) - lp32).abs().max()) < 0.5 and float((logp.reshape(-1) - lp32).abs().mean()) < 0.05
     # different draw index -> different noise; same call again from the same state -> identical (deterministic)
-    env2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="team", max_episode_steps=60); env2.reset()
+    env2 = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel, max_episode_steps=60); env2.reset()
     acts2 = torch.zeros_like(acts)
     env2.rollout_policy(pol.flat_param, T, seed=77, draw0=5, obs=torch.zeros_like(obs), actions=acts2, logp=torch.zeros_like(logp), values=torch.zeros_like(vals),
                         rewards=torch.zeros_like(rew), dones=torch.zeros_like(dones))
     assert torch.equal(acts2, acts)
     env.close(); ref.close(); env2.close()
+
+
+def test_closed_loop_policy_rollout_forms_draw_the_same_actions():
+    """The lane-per-env form keeps the lane-team form's Philox keying, Box-Muller mapping and log-prob summation: from the same state and
+    observation the first step's raw actions, log-probs and values are bit-identical (later steps differ by the env kernels' rounding)."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n, T = 2048, 2
+    torch.manual_seed(5)
+    pol = amd.ActorCritic(29, 7).cuda().flatten_()
+    with torch.no_grad():
+        pol.action_net.weight.mul_(30.0)
+    out = []
+    for kernel in ("team", "lane"):
+        env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel)
+        env.reset()
+        dev = env.device
+        obs = torch.zeros(T + 1, n, 29, device=dev); acts = torch.zeros(T, n, 7, device=dev)
+        logp = torch.zeros(T, n, device=dev); vals = torch.zeros(T, n, device=dev); rew = torch.zeros(T, n, device=dev)
+        dones = torch.zeros(T, n, dtype=torch.uint8, device=dev)
+        env.rollout_policy(pol.flat_param, T, seed=3, draw0=9, obs=obs, actions=acts, logp=logp, values=vals, rewards=rew, dones=dones)
+        torch.cuda.synchronize()
+        out.append((obs.clone(), acts.clone(), logp.clone(), vals.clone()))
+        env.close()
+    (o1, a1, l1, v1), (o2, a2, l2, v2) = out
+    # rows whose entry observation is the same MLP input in both forms (the forward kinematics of the two env kernels differ in the last
+    # fp32 bits; the MLP reads the observation rounded to bf16)
+    same = (o1[0].bfloat16() == o2[0].bfloat16()).all(dim=1)
+    assert int(same.sum()) > n // 2
+    assert torch.equal(a1[0][same], a2[0][same]) and torch.equal(l1[0][same], l2[0][same]) and torch.equal(v1[0][same], v2[0][same])
+    assert float((o1[1] - o2[1]).abs().max()) < 1e-4
