@@ -362,14 +362,69 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
                        const float* advantages, const float* returns, const int64_t* index, int64_t n, float clip_range, float ent_coef,
                        float vf_coef, int32_t normalize_advantage, float* flat_grad, float* stats4, void* workspace, void* stream);
 
-/* Gradient-norm clip + Adam on the flat parameter buffer, one launch (the torch.nn.utils.clip_grad_norm_ + torch.optim.Adam step of SB3's
+/* Gradient-norm clip + Adam on the flat parameter buffer (the torch.nn.utils.clip_grad_norm_ + torch.optim.Adam step of SB3's
  * PPO.train(); Adam with eps 1e-5, v2/rl_train.py:38 through SB3's defaults).  exp_avg / exp_avg_sq / step: torch.optim.Adam's state for
  * that parameter (step: ONE f32 on the device, as torch keeps it with capturable=True; incremented here).  hyper6 (device): lr, beta1,
  * beta2, eps, max_grad_norm (<= 0: no clipping), grad_scale (multiplies the gradient first: 1 / world size after a sum all-reduce).
- * flat_grad is left scaled and clipped, grad_norm_out (may be NULL) receives the norm before clipping.  ticket: one zero-initialised
- * device word the kernel uses and leaves zero. */
+ * flat_grad is left scaled and clipped, grad_norm_out (may be NULL) receives the norm before clipping.  The norm is complete before any
+ * gradient element is overwritten (one workgroup with a barrier up to 65,536 parameters, two launches above).  word: one device word of
+ * scratch (the large-buffer path passes the norm through it; contents undefined afterwards). */
 int amenv_ppo_adam_step(float* flat_params, float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6,
-                        float* grad_norm_out, uint32_t* ticket, void* stream);
+                        float* grad_norm_out, uint32_t* word, void* stream);
+
+/* ---- PID + minimum-snap baseline controller ------------------------------------------------------------
+ * The reference's hand-tuned controller, `v2/PID Controller/{pid_controller,trajGen3D,runsim}.py`, for N vehicles per launch on caller-owned
+ * device buffers of the CURRENT device.  `dtype` selects the arithmetic of the float buffers marked (dtype): AMENV_F64 = the logic gate
+ * pinned to the reference's recorded run (tests/golden/pid_helix.npz), AMENV_F32 = the product build. */
+typedef struct amenv_pid_params {
+  double dt;           /* control period the integrals are advanced by (runsim.py:28: 0.01; the waypoint env: 1/200) */
+  double mass, g;      /* params.py:10-11 */
+  double max_integral; /* pid_controller.py:34: 100 */
+  double gain[18];     /* [x, y, z, phi, theta, psi][k_p, k_d, k_i]  (pid_controller.py:16-21) */
+} amenv_pid_params;
+/* The committed gains and the reference quadrotor's mass / g; dt = 0.01. */
+int amenv_pid_default_params(amenv_pid_params* p);
+
+/* pid_controller.run (pid_controller.py:37-115) with Quadcopter.attitude() (model/quadcopter.py:57-59):
+ *   state    [n, 13] (dtype) position, velocity, quaternion (w, x, y, z), body rates = Quadcopter.state
+ *   des      [n, 11] (dtype) desired position, velocity, acceleration, yaw, yaw rate  (trajGen3D.DesiredState)
+ *   integral [n, 6]  (dtype) in/out: the module's integral memory (x, y, z, phi, theta, psi), clamped to +-max_integral
+ *   F_out [n], M_out [n, 3] (dtype): thrust and moments BEFORE the mixer;  rpy_out [n, 3] (dtype) or NULL: the attitude it used */
+int amenv_pid_run(const amenv_pid_params* p, int32_t dtype, const void* state, const void* des, void* integral, void* F_out, void* M_out,
+                  void* rpy_out, int64_t n, void* stream);
+
+/* trajGen3D.get_MST_coefficients / MST (:211-292) for n_traj trajectories of n_segments (1..16) 7th-order segments each:
+ *   waypoints [n_traj, n_segments + 1, 3] f64  ->  coeff [n_traj, 8 n_segments, 3] f64 (the reference's coeff_x / _y / _z as columns),
+ *   seg_time [n_traj, n_segments] = |w_i - w_i+1| / speed and seg_start [n_traj, n_segments + 1] = their running sum (:97-103).
+ * The 8n x 8n constraint matrix depends on n_segments only: it is inverted on the device (fp64 Gauss-Jordan, partial pivoting) into
+ * `workspace` (amenv_minsnap_workspace_bytes(n_segments) bytes, 8-byte aligned), then every trajectory is one small matrix product. */
+size_t amenv_minsnap_workspace_bytes(int32_t n_segments);
+int amenv_minsnap_solve(int32_t n_segments, int64_t n_traj, double speed, const double* waypoints, double* coeff, double* seg_time,
+                        double* seg_start, void* workspace, void* stream);
+/* trajGen3D.generate_trajectory (:76-187) for n_query (trajectory, time) pairs: query i evaluates trajectory traj[i] (traj NULL: i)
+ * at t[i] (f64) -> des [n_query, 11] (dtype): position, velocity, acceleration, yaw = yaw rate = 0 (:183-184); t == 0 returns the first
+ * waypoint at rest (:108-111), t past the last segment the last waypoint at rest (:121,176-179). */
+int amenv_minsnap_eval(int32_t n_segments, int64_t n_query, const double* coeff, const double* seg_time, const double* seg_start,
+                       const double* waypoints, const int64_t* traj, const double* t, int32_t dtype, void* des, void* stream);
+
+/* The controller wired to the waypoint environment as a closed-loop action source (the way runsim.py:26-31 flies its waypoint list):
+ * per episode a ONE-segment rest-to-rest minimum-snap trajectory from where the episode started to the waypoint at `speed` m/s, tracked
+ * by the PID; thrust scaled by mass, moments by inertia_ratio (this vehicle's inertia / the reference quadrotor's, per axis) and the
+ * moment vector scaled into the action box.  One launch: observation rows in, action rows out.
+ *   obs     [n, obs_dim] f32, v2 layout (rl_env_scaledObs.py:98-121), obs_dim >= 20 (29 with the arm)
+ *   done    [n] u8 or NULL: envs whose episode ended on the previous step (auto-reset => a new trajectory starts)
+ *   pstate  [n, 14] (dtype) in/out: t, start (3), goal (3), integrals (6), fresh; initialise to {0 x 13, 1}
+ *   actions [n, act_dim] f32, act_dim >= 4: thrust / (m g) in [0, 2], moments in [-1, 1]; entries 4.. (arm joints) = 0 (home)
+ * tool_mode = 1 (arm vehicle with AMENV_EE_TASK_TOOL, obs_dim 29): the position loop tracks the tool point instead of the base. */
+typedef struct amenv_pid_policy_params {
+  amenv_pid_params pid;
+  double speed;            /* m/s along the segment (runsim.py:27 flies 1.2) */
+  double moment_scale;     /* amenv_vehicle.moment_scale */
+  double inertia_ratio[3];
+  int32_t obs_dim, act_dim, tool_mode, reserved;
+} amenv_pid_policy_params;
+int amenv_pid_policy(const amenv_pid_policy_params* p, int32_t dtype, const float* obs, const uint8_t* done, void* pstate, float* actions,
+                     int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

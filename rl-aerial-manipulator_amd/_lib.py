@@ -57,6 +57,15 @@ class Stats(C.Structure):
         ("return_sum_q10", C.c_int64)]
 
 
+class PidParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("mass", C.c_double), ("g", C.c_double), ("max_integral", C.c_double), ("gain", C.c_double * 18)]
+
+
+class PidPolicyParams(C.Structure):
+    _fields_ = [("pid", PidParams), ("speed", C.c_double), ("moment_scale", C.c_double), ("inertia_ratio", C.c_double * 3),
+                ("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("tool_mode", C.c_int32), ("reserved", C.c_int32)]
+
+
 class AmenvError(RuntimeError):
     pass
 
@@ -98,6 +107,12 @@ SYMBOLS = {
     "amenv_ppo_mlp_workspace_bytes": (C.c_size_t, []),
     "amenv_ppo_mlp_step": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 6 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, _P, _P, _P, _P]),
     "amenv_ppo_adam_step": (C.c_int, [_P] * 5 + [C.c_int64, _P, _P, _P, _P]),
+    "amenv_pid_default_params": (C.c_int, [C.POINTER(PidParams)]),
+    "amenv_pid_run": (C.c_int, [C.POINTER(PidParams), C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "amenv_minsnap_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "amenv_minsnap_solve": (C.c_int, [C.c_int32, C.c_int64, C.c_double, _P, _P, _P, _P, _P, _P]),
+    "amenv_minsnap_eval": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    "amenv_pid_policy": (C.c_int, [C.POINTER(PidPolicyParams), C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     "amenv_gaussian_act": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_int64, _P]),
 }
 

@@ -1,6 +1,9 @@
 """PID + minimum-snap baseline controller, batched.
 
-Restates, for N vehicles at once on torch tensors (any device; the GPU-resident loops keep everything in HBM):
+For N vehicles at once.  On CUDA tensors every operation below is ONE launch of a hand-written HIP kernel through the C ABI
+(`amenv_pid_run`, `amenv_minsnap_solve` / `_eval`, `amenv_pid_policy`; csrc/amenv_baseline.hpp) -- no library is missing silently: without
+libamenv.so the call raises.  On CPU tensors the same arithmetic runs as the torch restatement in this file, which is what the CPU
+tests pin to the reference's recorded run and what the GPU tests compare the kernels with.
   * `PidController`     -- `PID Controller/pid_controller.py:37-115` (gains :16-21, integral clamp :34,66-67,107-108)
   * `MinSnapTrajectory` -- `PID Controller/trajGen3D.py`: `MST` (:211-292, 7th-order segments, the constraint rows in the
                            same order), `get_poly_cc` (:189-209), `generate_trajectory` (:76-187; its yaw bookkeeping ends
@@ -11,12 +14,33 @@ Restates, for N vehicles at once on torch tensors (any device; the GPU-resident 
 Pinned by tests/golden/pid_helix.npz (tools/gen_golden_pid.py: the unmodified reference modules run as runsim.py runs them).
 """
 
+import ctypes as C
+
 import torch
+
+from . import _lib
 
 # pid_controller.py:16-21
 GAINS = dict(x=(3.0, 30.0, 1.0), y=(3.0, 30.0, 1.0), z=(1000.0, 200.0, 10.0),
              phi=(160.0, 3.0, 1.0), theta=(160.0, 3.0, 1.0), psi=(80.0, 5.0, 1.0))   # (k_p, k_d, k_i)
 MAX_INTEGRAL = 100.0                                                                   # pid_controller.py:34
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dtype_code(t):
+    return _lib.F64 if t.dtype == torch.float64 else _lib.F32
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise _lib.AmenvError(f"{what} failed ({rc})")
 
 
 def rot_to_rpy(q):
@@ -42,6 +66,28 @@ class PidController:
         self.n, self.dt, self.mass, self.g = int(num_envs), float(dt), float(mass), float(g)
         self.gains = dict(GAINS if gains is None else gains)
         self.integral = torch.zeros(self.n, 6, device=device, dtype=dtype)   # x y z phi theta psi
+
+    def params(self):
+        """-> the C ABI's amenv_pid_params for this controller."""
+        p = _lib.PidParams(dt=self.dt, mass=self.mass, g=self.g, max_integral=MAX_INTEGRAL)
+        for k, name in enumerate(("x", "y", "z", "phi", "theta", "psi")):
+            p.gain[3 * k:3 * k + 3] = self.gains[name]
+        return p
+
+    def run_state(self, state, des):
+        """state [N, 13] (`Quadcopter.state`: p, v, q, body rates), des [N, 11] (pos, vel, acc, yaw, yaw rate) -> F [N], M [N, 3],
+        rpy [N, 3].  CUDA tensors: one launch of `amenv_pid_run` (fp64 or fp32 after the integral memory's dtype)."""
+        I = self.integral
+        state, des = state.to(I.dtype).contiguous(), des.to(I.dtype).contiguous()
+        if not I.is_cuda:
+            rpy = rot_to_rpy(state[:, 6:10])
+            F, M = self.run(state[:, 0:3], state[:, 3:6], rpy, state[:, 10:13], des[:, 0:3], des[:, 3:6], des[:, 6:9], des[:, 9], des[:, 10])
+            return F, M, torch.stack(rpy, -1)
+        n = state.shape[0]
+        F, M, rpy = I.new_empty(n), I.new_empty(n, 3), I.new_empty(n, 3)
+        _check(_lib.load().amenv_pid_run(C.byref(self.params()), _dtype_code(I), _p(state), _p(des), _p(I), _p(F), _p(M), _p(rpy), n, _stream(I)),
+               "amenv_pid_run")
+        return F, M, rpy
 
     def reset(self, mask=None):
         if mask is None:
@@ -93,10 +139,17 @@ class MinSnapTrajectory:
         self.batched = w.dim() == 3
         if not self.batched:
             w = w.unsqueeze(0)
+        w = w.contiguous()
         self.waypoints, self.speed = w, float(speed)
         n = w.shape[1] - 1
         self.n = n
         dev = w.device
+        if w.is_cuda:     # amenv_minsnap_solve: constraint matrix inverted on the device, one matrix product per trajectory
+            lib, nb = _lib.load(), w.shape[0]
+            self.coeff, self.T, self.S = w.new_empty(nb, 8 * n, 3), w.new_empty(nb, n), w.new_empty(nb, n + 1)
+            ws = torch.empty(lib.amenv_minsnap_workspace_bytes(n) // 8, dtype=torch.float64, device=dev)
+            _check(lib.amenv_minsnap_solve(n, nb, self.speed, _p(w), _p(self.coeff), _p(self.T), _p(self.S), _p(ws), _stream(w)), "amenv_minsnap_solve")
+            return
         A = torch.zeros(8 * n, 8 * n, dtype=torch.float64, device=dev)
         c0 = [poly_cc(8, k, 0.0, device=dev) for k in range(7)]
         c1 = [poly_cc(8, k, 1.0, device=dev) for k in range(7)]
@@ -120,6 +173,10 @@ class MinSnapTrajectory:
         """generate_trajectory(t, v, ...) -> pos, vel, acc [batch, 3], yaw, yawdot [batch] (both 0, :183-184)."""
         w, S, T = self.waypoints, self.S, self.T
         t = torch.as_tensor(t, dtype=torch.float64, device=w.device).expand(w.shape[0])
+        if w.is_cuda:
+            des = self.evaluate(t.contiguous())
+            out = (des[:, 0:3], des[:, 3:6], des[:, 6:9], des[:, 9], des[:, 10])
+            return out if self.batched else tuple(o[0] for o in out)
         idx = ((t.unsqueeze(-1) >= S).sum(-1) - 1).clamp(0, self.n - 1)             # :105
         Ti = T.gather(1, idx.unsqueeze(-1)).squeeze(-1)
         scale = (t - S.gather(1, idx.unsqueeze(-1)).squeeze(-1)) / Ti                 # :123
@@ -137,6 +194,31 @@ class MinSnapTrajectory:
         return out if self.batched else tuple(o[0] for o in out)
 
 
+    def _evaluate(self, t, traj=None, dtype=torch.float64):
+        """CUDA only: `amenv_minsnap_eval` for m (trajectory, time) queries -> des [m, 11] (pos, vel, acc, yaw, yaw rate) of `dtype`."""
+        w = self.waypoints
+        t = torch.as_tensor(t, dtype=torch.float64, device=w.device).contiguous()
+        if traj is not None:
+            traj = torch.as_tensor(traj, dtype=torch.int64, device=w.device).contiguous()
+        des = torch.empty(t.numel(), 11, dtype=dtype, device=w.device)
+        _check(_lib.load().amenv_minsnap_eval(self.n, t.numel(), _p(self.coeff), _p(self.T), _p(self.S), _p(w), _p(traj), _p(t), _dtype_code(des), _p(des),
+                                              _stream(w)), "amenv_minsnap_eval")
+        return des
+
+    def evaluate(self, t, traj=None, dtype=torch.float64):
+        """m queries at once: des [m, 11]; query i = trajectory traj[i] (None: trajectory i) at time t[i]."""
+        if self.waypoints.is_cuda:
+            return self._evaluate(t, traj, dtype)
+        t = torch.as_tensor(t, dtype=torch.float64)
+        idx = torch.arange(t.numel()) if traj is None else torch.as_tensor(traj, dtype=torch.int64)
+        one = MinSnapTrajectory.__new__(MinSnapTrajectory)
+        one.__dict__.update(self.__dict__)
+        one.batched = True
+        one.waypoints, one.coeff, one.T, one.S = self.waypoints[idx], self.coeff[idx], self.T[idx], self.S[idx]
+        p, v, a, yaw, yawdot = one.desired_state(t)
+        return torch.cat([p, v, a, yaw.unsqueeze(-1), yawdot.unsqueeze(-1)], -1).to(dtype)
+
+
 class PidWaypointPolicy:
     """Closed-loop baseline for the waypoint environment: `predict(obs, done)` -> actions [N, 4] from the 20-D observation
     alone (position, velocity, quaternion, body rates and the vector to the current waypoint are all in it,
@@ -149,8 +231,15 @@ class PidWaypointPolicy:
     QUAD_INERTIA = (2.5e-4, 2.32e-4, 3.738e-4)     # simul_files/model/params.py
 
     def __init__(self, num_envs, dt=1.0 / 200.0, mass=0.18, g=9.81, moment_scale=0.1, inertia_diag=None, speed=0.6,
-                 device="cpu", dtype=torch.float32, gains=None):
+                 device="cpu", dtype=torch.float32, gains=None, act_dim=4, tool_mode=False):
         self.pid = PidController(num_envs, dt, mass, g, device, dtype, gains)
+        self.act_dim, self.tool_mode = int(act_dim), bool(tool_mode)
+        # CUDA: the whole predict() is one launch of amenv_pid_policy on this state block [N, 14] = t, start, goal, integrals, fresh
+        self.pstate = None
+        if torch.device(device).type == "cuda":
+            self.pstate = torch.zeros(num_envs, 14, device=device, dtype=dtype)
+            self.pstate[:, 13] = 1.0
+            self.inertia_ratio = [a / b for a, b in zip(self.QUAD_INERTIA if inertia_diag is None else inertia_diag, self.QUAD_INERTIA)]
         self.dt, self.speed, self.mass, self.g, self.moment_scale = float(dt), float(speed), float(mass), float(g), float(moment_scale)
         inertia = self.QUAD_INERTIA if inertia_diag is None else inertia_diag
         self.m_gain = torch.tensor([a / b for a, b in zip(inertia, self.QUAD_INERTIA)], device=device, dtype=dtype)
@@ -161,14 +250,20 @@ class PidWaypointPolicy:
         self.high = torch.tensor([2.0, 1.0, 1.0, 1.0], device=device, dtype=dtype)
 
     @classmethod
-    def for_env(cls, env, speed=0.6):
+    def for_env(cls, env, speed=0.6, dtype=torch.float32):
         v = env.cfg.vehicle
+        arm = v.n_joints > 0
         return cls(env.num_envs, dt=env.cfg.task.dt, mass=v.mass, g=v.g, moment_scale=v.moment_scale,
-                   inertia_diag=(v.inertia[0], v.inertia[4], v.inertia[8]), speed=speed, device=env.device)
+                   inertia_diag=(v.inertia[0], v.inertia[4], v.inertia[8]), speed=speed, device=env.device, dtype=dtype,
+                   act_dim=env.act_dim, tool_mode=arm and env.cfg.task.ee_task == _lib.EE_TASK_TOOL)
 
     @torch.no_grad()
     def predict(self, obs, done=None):
         """obs [N, >=16] f32 (v2 layout), done [N] from the previous step (those envs were auto-reset: new episode)."""
+        if self.pstate is not None:
+            return self._predict_hip(obs, done)
+        if self.act_dim != 4 or self.tool_mode:
+            raise NotImplementedError("the torch restatement covers the rigid vehicles (4 actions); the arm runs on the HIP kernel")
         o = obs.to(self.t.dtype)
         if done is not None:
             self.fresh |= done.bool()
@@ -207,3 +302,17 @@ class PidWaypointPolicy:
         am = am / am.abs().amax(dim=-1, keepdim=True).clamp(min=1.0)
         a = torch.cat([(F / (self.mass * self.g)).unsqueeze(-1), am], -1)
         return torch.minimum(torch.maximum(a, self.low), self.high).to(torch.float32)
+
+    def _predict_hip(self, obs, done):
+        n, pid = self.pstate.shape[0], self.pid
+        obs = obs.contiguous()
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.shape[0] == n and obs.shape[1] >= (29 if self.tool_mode else 20)
+        if done is not None:
+            done = done.to(torch.uint8).contiguous()
+        p = _lib.PidPolicyParams(pid=pid.params(), speed=self.speed, moment_scale=self.moment_scale, obs_dim=obs.shape[1], act_dim=self.act_dim,
+                                 tool_mode=int(self.tool_mode))
+        p.inertia_ratio[:] = self.inertia_ratio
+        act = torch.empty(n, self.act_dim, device=obs.device, dtype=torch.float32)
+        _check(_lib.load().amenv_pid_policy(C.byref(p), _dtype_code(self.pstate), _p(obs), _p(done), _p(self.pstate), _p(act), n, _stream(obs)),
+               "amenv_pid_policy")
+        return act

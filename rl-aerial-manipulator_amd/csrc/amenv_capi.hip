@@ -22,6 +22,7 @@
 #include "amenv_policy.hpp"
 #include "amenv_train.hpp"
 #include "amenv_mlp_train.hpp"
+#include "amenv_baseline.hpp"
 
 using namespace amenv_dev;
 
@@ -1011,9 +1012,95 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
 int amenv_ppo_adam_step(float* flat_params, float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6, float* grad_norm_out,
                         uint32_t* ticket, void* stream) {
   if (!flat_params || !flat_grad || !exp_avg || !exp_avg_sq || !step || !hyper6 || !ticket || n <= 0) return AMENV_ERR_INVALID;
-  const int blocks = int(std::min<int64_t>(kAdamMaxBlocks, (n + kAdamBlock - 1) / kAdamBlock));
-  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(kAdamBlock), 0, (hipStream_t)stream, flat_params, flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6,
-                     grad_norm_out, ticket);
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= kAdamSmall) {   // one workgroup: norm, barrier, update
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(1), dim3(kAdamBlock), 0, s, flat_params, flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6, grad_norm_out);
+  } else {                 // a kernel boundary between the norm and the first overwritten gradient element
+    const int blocks = int(std::min<int64_t>(kAdamMaxBlocks, (n + kAdamBlock - 1) / kAdamBlock));
+    hipLaunchKernelGGL(adam_norm_kernel, dim3(1), dim3(kAdamBlock), 0, s, flat_grad, step, (int64_t)n, hyper6, grad_norm_out, reinterpret_cast<float*>(ticket));
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(blocks), dim3(kAdamBlock), 0, s, flat_params, flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6,
+                       reinterpret_cast<const float*>(ticket));
+  }
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+// ---- PID + minimum-snap baseline controller (row f4; csrc/amenv_baseline.hpp) ---------------------------------------------------------
+int amenv_pid_default_params(amenv_pid_params* p) {
+  if (!p) return AMENV_ERR_INVALID;
+  static const double kGains[18] = {3.0, 30.0, 1.0, 3.0, 30.0, 1.0, 1000.0, 200.0, 10.0,      // x, y, z       (pid_controller.py:16-18)
+                                    160.0, 3.0, 1.0, 160.0, 3.0, 1.0, 80.0, 5.0, 1.0};        // phi theta psi (:19-21)
+  p->dt = 0.01; p->mass = 0.18; p->g = 9.81; p->max_integral = 100.0;
+  std::memcpy(p->gain, kGains, sizeof(kGains));
+  return AMENV_OK;
+}
+
+namespace {
+bool pid_params_ok(const amenv_pid_params* p) { return p && p->dt > 0.0 && p->mass > 0.0 && p->g > 0.0 && p->max_integral >= 0.0; }
+PidParams to_dev(const amenv_pid_params& p) {
+  PidParams d;
+  d.dt = p.dt; d.mass = p.mass; d.g = p.g; d.max_integral = p.max_integral;
+  for (int k = 0; k < 6; k++) for (int j = 0; j < 3; j++) d.gain[k][j] = p.gain[3 * k + j];
+  return d;
+}
+}  // namespace
+
+int amenv_pid_run(const amenv_pid_params* p, int32_t dtype, const void* state, const void* des, void* integral, void* F_out, void* M_out,
+                  void* rpy_out, int64_t n, void* stream) {
+  if (!pid_params_ok(p) || !state || !des || !integral || !F_out || !M_out || n <= 0 || (dtype != AMENV_F32 && dtype != AMENV_F64)) return AMENV_ERR_INVALID;
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  const PidParams d = to_dev(*p);
+  if (dtype == AMENV_F64)
+    hipLaunchKernelGGL(pid_run_kernel<double>, grid, block, 0, (hipStream_t)stream, d, (const double*)state, (const double*)des, (double*)integral,
+                       (double*)F_out, (double*)M_out, (double*)rpy_out, (int64_t)n);
+  else
+    hipLaunchKernelGGL(pid_run_kernel<float>, grid, block, 0, (hipStream_t)stream, d, (const float*)state, (const float*)des, (float*)integral,
+                       (float*)F_out, (float*)M_out, (float*)rpy_out, (int64_t)n);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+size_t amenv_minsnap_workspace_bytes(int32_t n_segments) {
+  return (n_segments < 1 || n_segments > 16) ? 0 : size_t(8 * n_segments) * size_t(10 * n_segments) * sizeof(double);
+}
+
+int amenv_minsnap_solve(int32_t n_segments, int64_t n_traj, double speed, const double* waypoints, double* coeff, double* seg_time,
+                        double* seg_start, void* workspace, void* stream) {
+  if (n_segments < 1 || n_segments > 16 || n_traj <= 0 || !(speed > 0.0) || !waypoints || !coeff || !seg_time || !seg_start || !workspace)
+    return AMENV_ERR_INVALID;
+  hipLaunchKernelGGL(minsnap_inverse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (int)n_segments, (double*)workspace);
+  const int64_t rows = n_traj * 8 * n_segments;
+  hipLaunchKernelGGL(minsnap_coeff_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)n_segments, (int64_t)n_traj,
+                     speed, (const double*)workspace, waypoints, coeff, seg_time, seg_start);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+int amenv_minsnap_eval(int32_t n_segments, int64_t n_query, const double* coeff, const double* seg_time, const double* seg_start,
+                       const double* waypoints, const int64_t* traj, const double* t, int32_t dtype, void* des, void* stream) {
+  if (n_segments < 1 || n_segments > 16 || n_query <= 0 || !coeff || !seg_time || !seg_start || !waypoints || !t || !des ||
+      (dtype != AMENV_F32 && dtype != AMENV_F64))
+    return AMENV_ERR_INVALID;
+  const dim3 grid((unsigned)((n_query + 63) / 64)), block(64);
+  if (dtype == AMENV_F64)
+    hipLaunchKernelGGL(minsnap_eval_kernel<double>, grid, block, 0, (hipStream_t)stream, (int)n_segments, (int64_t)n_query, coeff, seg_time, seg_start,
+                       waypoints, traj, t, (double*)des);
+  else
+    hipLaunchKernelGGL(minsnap_eval_kernel<float>, grid, block, 0, (hipStream_t)stream, (int)n_segments, (int64_t)n_query, coeff, seg_time, seg_start,
+                       waypoints, traj, t, (float*)des);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
+int amenv_pid_policy(const amenv_pid_policy_params* p, int32_t dtype, const float* obs, const uint8_t* done, void* pstate, float* actions,
+                     int64_t n, void* stream) {
+  if (!p || !pid_params_ok(&p->pid) || !obs || !pstate || !actions || n <= 0 || (dtype != AMENV_F32 && dtype != AMENV_F64) || !(p->speed > 0.0) ||
+      !(p->moment_scale > 0.0) || p->obs_dim < 20 || p->act_dim < 4 || p->act_dim > 16 || (p->tool_mode != 0 && p->obs_dim < 29))
+    return AMENV_ERR_INVALID;
+  PidPolicyParams d;
+  d.pid = to_dev(p->pid);
+  d.speed = p->speed; d.moment_scale = p->moment_scale;
+  for (int k = 0; k < 3; k++) d.m_gain[k] = p->inertia_ratio[k];
+  d.obs_dim = p->obs_dim; d.act_dim = p->act_dim; d.tool_mode = p->tool_mode ? 1 : 0; d.pad = 0;
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  if (dtype == AMENV_F64) hipLaunchKernelGGL(pid_policy_kernel<double>, grid, block, 0, (hipStream_t)stream, d, obs, done, (double*)pstate, actions, (int64_t)n);
+  else hipLaunchKernelGGL(pid_policy_kernel<float>, grid, block, 0, (hipStream_t)stream, d, obs, done, (float*)pstate, actions, (int64_t)n);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

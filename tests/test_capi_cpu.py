@@ -35,6 +35,24 @@ def test_struct_layout_matches_header():
     assert (od.value, ad.value) == (29, 7)
 
 
+def test_pid_default_params_are_the_reference_gains():
+    """amenv_pid_default_params (host only) against the gains committed in `PID Controller/pid_controller.py:16-21,34` as baselines.py
+    restates them; bad arguments to the launchers are refused before anything touches a device."""
+    from rl_aerial_manipulator_amd.baselines import GAINS, MAX_INTEGRAL
+    p = amd._lib.PidParams()
+    assert amd._lib.load().amenv_pid_default_params(C.byref(p)) == 0 and amd._lib.load().amenv_pid_default_params(None) == -1
+    assert (p.dt, p.mass, p.g, p.max_integral) == (0.01, 0.18, 9.81, MAX_INTEGRAL)
+    for k, name in enumerate(("x", "y", "z", "phi", "theta", "psi")):
+        assert tuple(p.gain[3 * k:3 * k + 3]) == GAINS[name]
+    assert C.sizeof(amd._lib.PidParams) == 22 * 8 and C.sizeof(amd._lib.PidPolicyParams) == 22 * 8 + 5 * 8 + 16
+    L = amd._lib.load()
+    assert L.amenv_minsnap_workspace_bytes(4) == 32 * 40 * 8 and L.amenv_minsnap_workspace_bytes(0) == 0 and L.amenv_minsnap_workspace_bytes(17) == 0
+    assert L.amenv_pid_run(C.byref(p), 0, None, None, None, None, None, None, 4, None) == -1
+    assert L.amenv_minsnap_solve(0, 1, 1.2, None, None, None, None, None, None) == -1
+    assert L.amenv_minsnap_eval(4, 0, None, None, None, None, None, None, 1, None, None) == -1
+    assert L.amenv_pid_policy(None, 0, None, None, None, None, 1, None) == -1
+
+
 def test_default_quad_equals_oracle_constants():
     """Product-side constants (amenv_default_config) vs the oracle's independent restatement of params.py."""
     a = amd._lib.default_config("quad", 1)

@@ -526,14 +526,14 @@ def test_fused_mlp_step_index_gather_is_bit_identical_and_deterministic():
     assert float(g_idx.abs().max()) > 0
 
 
-@pytest.mark.parametrize("world_scale,max_norm", [(1, 0.5), (2, 0.5), (1, None)])
-def test_fused_adam_step_matches_torch_adam(world_scale, max_norm):
+@pytest.mark.parametrize("world_scale,max_norm,n", [(1, 0.5, 33039), (2, 0.5, 33039), (1, None, 33039), (1, 0.5, 300001)])
+def test_fused_adam_step_matches_torch_adam(world_scale, max_norm, n):
     """amenv_ppo_adam_step against clip_grad_norm_-style scaling + torch.optim.Adam over several steps: parameters, both moments, the
-    step counter and the reported norm."""
+    step counter and the reported norm.  n = 33039: the one-workgroup kernel (the reference policy's size); 300001: norm and update as
+    two launches."""
     from rl_aerial_manipulator_amd import _lib as L_
     import ctypes as C_
     torch.manual_seed(0)
-    n = 33039
     p_ref = torch.randn(n, device="cuda", dtype=torch.float64) * 0.3
     p_hip = p_ref.float().clone()
     leaf = p_ref.clone().requires_grad_(True)
@@ -556,12 +556,37 @@ def test_fused_adam_step_matches_torch_adam(world_scale, max_norm):
         assert abs(float(gn) - float(norm)) < 1e-5 * float(norm)
         assert torch.allclose(gh.double(), gd, rtol=1e-5, atol=1e-9)
     st = opt.state[leaf]
-    assert float(stp) == 25.0 and int(ticket) == 0
+    assert float(stp) == 25.0
     assert torch.allclose(m.double(), st["exp_avg"], rtol=1e-4, atol=1e-7)
     assert torch.allclose(v.double(), st["exp_avg_sq"], rtol=1e-4, atol=1e-12)
     # 25 Adam steps of at most lr each: the fp32 kernel tracks the fp64 optimiser to a small fraction of one step
     assert float((p_hip.double() - leaf.detach()).abs().max()) < 2e-4 * 0.02
     assert float((p_hip.double() - p_ref).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("n", [33039, 300001])
+def test_fused_adam_step_norm_is_complete_before_any_gradient_is_clipped(n):
+    """The clip factor comes from the norm of the WHOLE gradient as it was on entry: repeated from the same inputs with the clip active,
+    every run gives the same bits, and the clipped gradient has norm max_grad_norm.  (A multi-workgroup version whose workgroups each
+    summed the whole buffer and then overwrote their slice could read slices that were already clipped: found by the bit-exact
+    RCCL-exchange test below failing once.)"""
+    from rl_aerial_manipulator_amd import _lib as L_
+    import ctypes as C_
+    torch.manual_seed(1)
+    g0 = torch.randn(n, device="cuda") * 0.3                          # norm >> 0.5: clip factor ~ 0.01
+    p0 = torch.randn(n, device="cuda")
+    hyper = torch.tensor([2e-4, 0.9, 0.999, 1e-5, 0.5, 1.0], device="cuda")
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ptr = lambda t: C_.c_void_p(t.data_ptr())  # noqa: E731
+    first = None
+    for _ in range(200):
+        p, g, m, v, stp, gn = p0.clone(), g0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros((), device="cuda"), torch.zeros(1, device="cuda")
+        assert L_.load().amenv_ppo_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(stp), n, ptr(hyper), ptr(gn), ptr(word), None) == 0
+        if first is None:
+            first = (p.clone(), g.clone(), float(gn))
+            assert abs(float(g.double().norm()) - 0.5) < 1e-5 and abs(first[2] - float(g0.double().norm())) < 1e-4 * first[2]
+        else:
+            assert torch.equal(p, first[0]) and torch.equal(g, first[1]) and float(gn) == first[2]
 
 
 def test_ppo_update_fused_path_trains_like_the_torch_path():
