@@ -47,7 +47,7 @@ def parse(argv=None):
     ap.add_argument("--vehicle", default="hexa_arm", choices=["quad", "hexa", "hexa_arm"],
                     help="hexa_arm = BASELINE configs[2], the configuration the metric is quoted on; hexa = configs[1]; quad = the reference vehicle")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"])
-    ap.add_argument("--kernel", default="auto", choices=["auto", "lane", "helper", "team"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "lane", "helper", "team", "staged"])
     ap.add_argument("--actions", default="hover", choices=["hover", "uniform"], help="SURVEY 8d action sets B (hover-centred) / A (uniform stress)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--block-size", type=int, default=0)

@@ -56,7 +56,9 @@ extern "C" {
 #define AMENV_KERNEL_AUTO 0
 #define AMENV_KERNEL_LANE 1   /* one lane per env, one wavefront per 64-env tile                                      */
 #define AMENV_KERNEL_HELPER 2 /* LANE + helper wavefronts per tile (reset RNG words, observation rows, arm link 3)     */
-#define AMENV_KERNEL_TEAM 3   /* a team of 4 lanes (one DPP quad) per env: vector components across lanes              */
+#define AMENV_KERNEL_TEAM 3   /* a team of 16 lanes (one DPP row) per env: 4 bodies x 4 vector components across lanes */
+#define AMENV_KERNEL_STAGED 4 /* arm vehicle: the four RK4 stages' joint-configuration work on four wavefronts side by side,
+                                 the base dynamics on their 36-number aggregates on a fifth (not bit-identical to LANE)  */
 
 /* amenv_task.ee_task (arm vehicles only; ignored without an arm) */
 #define AMENV_EE_TASK_BASE 0 /* waypoint distance measured from the base position, as the reference's quadrotor task   */

@@ -16,8 +16,8 @@ F_FINAL_YAW, F_LAST_DISTANCE, F_EP_RETURN, F_WP0 = 13, 14, 15, 16
 I_STEP, I_COUNTER, I_FLAGS, I_EPISODE, I_NFIELDS = 0, 1, 2, 3, 4
 FLAGBIT_FWR, FLAGBIT_COUNTER_ACTIVE = 256, 512
 TASK_V2_SCALED20, TASK_V1_SCALED17, TASK_V1_RAW17 = 0, 1, 2
-KERNEL_AUTO, KERNEL_LANE, KERNEL_HELPER, KERNEL_TEAM = 0, 1, 2, 3
-KERNELS = {"auto": KERNEL_AUTO, "lane": KERNEL_LANE, "helper": KERNEL_HELPER, "team": KERNEL_TEAM}
+KERNEL_AUTO, KERNEL_LANE, KERNEL_HELPER, KERNEL_TEAM, KERNEL_STAGED = 0, 1, 2, 3, 4
+KERNELS = {"auto": KERNEL_AUTO, "lane": KERNEL_LANE, "helper": KERNEL_HELPER, "team": KERNEL_TEAM, "staged": KERNEL_STAGED}
 EE_TASK_BASE, EE_TASK_TOOL = 0, 1
 TASKS = {"v2": TASK_V2_SCALED20, "v1_scaled": TASK_V1_SCALED17, "v1_raw": TASK_V1_RAW17}
 

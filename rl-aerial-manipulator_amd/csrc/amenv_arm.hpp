@@ -521,4 +521,265 @@ __device__ __forceinline__ void dynamics_arm(const HotParams<T, NROT>& P, const 
   for (int k = 0; k < 3; k++) { e.th[k] = y[13 + k]; e.thd[k] = y[16 + k]; }
 }
 
+// ---- Staged form (step_kernel_armk, amenv_kernels.hpp): joint-configuration aggregates, then the base dynamics on them ---------------
+// The joint servos do not feel the base, so the joint state of all four RK4 stages is known from (th, thd, cmd) alone, and every sum
+// over the links in the equations at the top of this file can be taken BEFORE the base's angular velocity w is known:
+//   fb = sum m_k b_k                                    = w x (w x S) + 2 w x U + Aa            U = sum m_k u_k,  Aa = sum m_k a_k
+//   nb = sum [ m_k r_k x b_k + J_k (al_k + w x w_k) + W_k x (J_k W_k) ]  (base body included)
+//      = w x (I_O w) + G w + w x H + Tn
+//        G  = sum 2 m_k ((u_k . r_k) 1 - u_k r_k^T) - (D_k + D_k^T),  D_k = J_k [w_k]x      (r x (2 w x u);  J (w x w_k) and w_k x (J w))
+//        H  = sum J_k w_k                                                                      (w x (J w_k))
+//        Tn = sum m_k r_k x a_k + J_k al_k + w_k x (J_k w_k)
+//   (sum m_k r_k x (w x (w x r_k)) + w x (J_k w) = w x (I_O w): the point-mass and the link inertias are the ones I_O sums anyway.)
+// 36 numbers per stage (S, U, Aa, I_O, G, H, Tn and the scaled adjugate of the composite inertia I_c) carry a stage's joint
+// configuration to the base dynamics, which is then ~160 instructions per stage instead of ~960.  The identity is exact (checked in
+// fp64 against the oracle's RHS to 2e-15); in fp32 the sums associate differently from arm_rhs_body, so this form is not bit-identical
+// to the lane kernel -- same gate (<= 2e-6 rel per step against the fp64 oracle).  z,x,x arm, fp32 or fp64.
+constexpr int kAggSlots = 36;
+enum { AG_S = 0, AG_U = 3, AG_A = 6, AG_IO = 9, AG_G = 15, AG_H = 24, AG_T = 27, AG_C = 30 };
+
+template <typename T>
+__device__ __forceinline__ T servo_(const ArmParams<T>& A, T cmd, T th, T td) { return clamp_(fma_(A.kp, cmd - th, -(A.kd * td)), -A.amax, A.amax); }
+
+template <typename T, typename PT>
+__device__ __forceinline__ void arm_kin_aggregates(const PT& P, const ArmParams<T>& A, const T* th, const T* td, const T* tdd, T* g) {
+  V3<T> S{T(0), T(0), T(0)}, U = S, Aa = S, H = S, Tn = S;
+  T IO[6] = {P.Ixx, P.Ixy, P.Ixz, P.Iyy, P.Iyz, P.Izz};
+  T G[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+  // one link: CoM position / velocity / acceleration relative to the body frame, inertia (body axes, xx xy xz yy yz zz), relative
+  // angular velocity / acceleration.  ZONLY: w = (0, 0, w.z), al = (0, 0, al.z) (link 1 of the z,x,x arm).
+  auto add_link = [&](auto zonly, T m, V3<T> r, V3<T> u, V3<T> a_, const T* J, V3<T> w, V3<T> al) {
+    constexpr bool ZONLY = decltype(zonly)::value;
+    S = S + m * r; U = U + m * u; Aa = Aa + m * a_;
+    const T r2 = dot(r, r);
+    IO[0] += J[0] + m * (r2 - r.x * r.x); IO[1] += J[1] - m * (r.x * r.y); IO[2] += J[2] - m * (r.x * r.z);
+    IO[3] += J[3] + m * (r2 - r.y * r.y); IO[4] += J[4] - m * (r.y * r.z); IO[5] += J[5] + m * (r2 - r.z * r.z);
+    const T m2 = m + m, d = m2 * dot(u, r);
+    const V3<T> mu = m2 * u;
+    T E00, E11, E22, E01, E02, E12;   // D + D^T
+    V3<T> Jw, Jal;
+    if constexpr (ZONLY) {
+      E00 = T(2) * (w.z * J[1]); E11 = -E00; E22 = T(0);
+      E01 = w.z * (J[3] - J[0]); E02 = w.z * J[4]; E12 = -(w.z * J[2]);
+      Jw = V3<T>{w.z * J[2], w.z * J[4], w.z * J[5]};
+      Jal = V3<T>{al.z * J[2], al.z * J[4], al.z * J[5]};
+    } else {
+      E00 = T(2) * fma_(w.z, J[1], -(w.y * J[2])); E11 = T(2) * fma_(w.x, J[4], -(w.z * J[1])); E22 = T(2) * fma_(w.y, J[2], -(w.x * J[4]));
+      E01 = fma_(w.x, J[2], -(w.z * J[0])) + fma_(w.z, J[3], -(w.y * J[4]));
+      E02 = fma_(w.y, J[0], -(w.x * J[1])) + fma_(w.z, J[4], -(w.y * J[5]));
+      E12 = fma_(w.y, J[1], -(w.x * J[3])) + fma_(w.x, J[5], -(w.z * J[2]));
+      Jw = V3<T>{dot3_(J[0], J[1], J[2], w.x, w.y, w.z), dot3_(J[1], J[3], J[4], w.x, w.y, w.z), dot3_(J[2], J[4], J[5], w.x, w.y, w.z)};
+      Jal = V3<T>{dot3_(J[0], J[1], J[2], al.x, al.y, al.z), dot3_(J[1], J[3], J[4], al.x, al.y, al.z), dot3_(J[2], J[4], J[5], al.x, al.y, al.z)};
+    }
+    G[0] += (d - mu.x * r.x) - E00; G[1] += -(mu.x * r.y) - E01; G[2] += -(mu.x * r.z) - E02;
+    G[3] += -(mu.y * r.x) - E01; G[4] += (d - mu.y * r.y) - E11; G[5] += -(mu.y * r.z) - E12;
+    G[6] += -(mu.z * r.x) - E02; G[7] += -(mu.z * r.y) - E12; G[8] += (d - mu.z * r.z) - E22;
+    H = H + Jw;
+    V3<T> wJw;
+    if constexpr (ZONLY) wJw = V3<T>{-(w.z * Jw.y), w.z * Jw.x, T(0)};
+    else wJw = cross(w, Jw);
+    Tn = Tn + m * cross(r, a_) + Jal + wJw;
+  };
+  // link 1: joint 1 about z at the start of the chain
+  T s0, c0;
+  sincos_(th[0], s0, c0);
+  const T wz = td[0], az = tdd[0];
+  const V3<T> o0{A.jo[0][0], A.jo[0][1], A.jo[0][2]};
+  {
+    const T lx = A.lc[0][0], ly = A.lc[0][1], lz = A.lc[0][2];
+    const V3<T> Rc{fma_(c0, lx, -(s0 * ly)), fma_(s0, lx, c0 * ly), lz};
+    const V3<T> u{-(wz * Rc.y), wz * Rc.x, T(0)};
+    const V3<T> a_{fma_(-az, Rc.y, -(wz * u.y)), fma_(az, Rc.x, wz * u.x), T(0)};
+    const T Ixx = A.li[0][0], Ixy = A.li[0][1], Ixz = A.li[0][2], Iyy = A.li[0][3], Iyz = A.li[0][4], Izz = A.li[0][5];
+    const T q00 = fma_(c0, Ixx, -(s0 * Ixy)), q01 = fma_(c0, Ixy, -(s0 * Iyy)), q02 = fma_(c0, Ixz, -(s0 * Iyz));
+    const T q10 = fma_(s0, Ixx, c0 * Ixy), q11 = fma_(s0, Ixy, c0 * Iyy), q12 = fma_(s0, Ixz, c0 * Iyz);
+    const T J[6] = {fma_(q00, c0, -(q01 * s0)), fma_(q00, s0, q01 * c0), q02, fma_(q10, s0, q11 * c0), q12, Izz};
+    add_link(std::true_type{}, A.lm[0], o0 + Rc, u, a_, J, V3<T>{T(0), T(0), wz}, V3<T>{T(0), T(0), az});
+  }
+  // chain at joint 2 (axis x of Rz(th1)), then R = Rz(th1) Rx(th2)
+  M3<T> R;
+  V3<T> p, pd, pdd, w, al;
+  {
+    const T ox = A.jo[1][0], oy = A.jo[1][1], oz = A.jo[1][2];
+    const V3<T> Ro{fma_(c0, ox, -(s0 * oy)), fma_(s0, ox, c0 * oy), oz};
+    pd = V3<T>{-(wz * Ro.y), wz * Ro.x, T(0)};
+    pdd = V3<T>{fma_(-az, Ro.y, -(wz * pd.y)), fma_(az, Ro.x, wz * pd.x), T(0)};
+    p = o0 + Ro;
+    al = V3<T>{fma_(tdd[1], c0, -(td[1] * (wz * s0))), fma_(tdd[1], s0, td[1] * (wz * c0)), az};
+    w = V3<T>{td[1] * c0, td[1] * s0, wz};
+    T s1, c1;
+    sincos_(th[1], s1, c1);
+    R = M3<T>{{c0, -(c1 * s0), s1 * s0, s0, c1 * c0, -(s1 * c0), T(0), s1, c1}};
+  }
+  auto link = [&](int k) {
+    const V3<T> Rc = mul(R, V3<T>{A.lc[k][0], A.lc[k][1], A.lc[k][2]});
+    const V3<T> wRc = cross(w, Rc);
+    const V3<T> r = p + Rc, u = pd + wRc, a_ = pdd + cross(al, Rc) + cross(w, wRc);
+    const M3<T> Ik{{A.li[k][0], A.li[k][1], A.li[k][2], A.li[k][1], A.li[k][3], A.li[k][4], A.li[k][2], A.li[k][4], A.li[k][5]}};
+    const M3<T> RI = mul(R, Ik);
+    const T J[6] = {dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[0], R.m[1], R.m[2]), dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[3], R.m[4], R.m[5]),
+                    dot3_(RI.m[0], RI.m[1], RI.m[2], R.m[6], R.m[7], R.m[8]), dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[3], R.m[4], R.m[5]),
+                    dot3_(RI.m[3], RI.m[4], RI.m[5], R.m[6], R.m[7], R.m[8]), dot3_(RI.m[6], RI.m[7], RI.m[8], R.m[6], R.m[7], R.m[8])};
+    add_link(std::false_type{}, A.lm[k], r, u, a_, J, w, al);
+  };
+  link(1);
+  {  // across joint 3 (axis x of the current frame = column 0 of R)
+    const V3<T> Ro = mul(R, V3<T>{A.jo[2][0], A.jo[2][1], A.jo[2][2]});
+    const V3<T> wRo = cross(w, Ro);
+    pd = pd + wRo;
+    pdd = pdd + cross(al, Ro) + cross(w, wRo);
+    p = p + Ro;
+    const V3<T> z{R.m[0], R.m[3], R.m[6]};
+    al = al + tdd[2] * z + td[2] * cross(w, z);
+    w = w + td[2] * z;
+    rotate_about_column<0>(R, th[2]);
+  }
+  link(2);
+  // composite inertia about the system CoM and its adjugate / determinant: wd = C (n - S x f / mtot)
+  const T S2 = dot(S, S), im = A.inv_mtot;
+  const T a = IO[0] - (S2 - S.x * S.x) * im, bq = IO[1] + (S.x * S.y) * im, c = IO[2] + (S.x * S.z) * im;
+  const T dd = IO[3] - (S2 - S.y * S.y) * im, e = IO[4] + (S.y * S.z) * im, ff = IO[5] - (S2 - S.z * S.z) * im;
+  const T c00 = fma_(dd, ff, -(e * e)), c01 = fma_(c, e, -(bq * ff)), c02 = fma_(bq, e, -(c * dd));
+  const T c11 = fma_(a, ff, -(c * c)), c12 = fma_(bq, c, -(a * e)), c22 = fma_(a, dd, -(bq * bq));
+  const T idet = rcp_(fma_(a, c00, fma_(bq, c01, c * c02)));
+  g[AG_S] = S.x; g[AG_S + 1] = S.y; g[AG_S + 2] = S.z; g[AG_U] = U.x; g[AG_U + 1] = U.y; g[AG_U + 2] = U.z;
+  g[AG_A] = Aa.x; g[AG_A + 1] = Aa.y; g[AG_A + 2] = Aa.z;
+#pragma unroll
+  for (int q = 0; q < 6; q++) g[AG_IO + q] = IO[q];
+#pragma unroll
+  for (int q = 0; q < 9; q++) g[AG_G + q] = G[q];
+  g[AG_H] = H.x; g[AG_H + 1] = H.y; g[AG_H + 2] = H.z; g[AG_T] = Tn.x; g[AG_T + 1] = Tn.y; g[AG_T + 2] = Tn.z;
+  g[AG_C] = idet * c00; g[AG_C + 1] = idet * c01; g[AG_C + 2] = idet * c02; g[AG_C + 3] = idet * c11; g[AG_C + 4] = idet * c12; g[AG_C + 5] = idet * c22;
+}
+
+// What one stage wave of step_kernel_armk does: joint state of RK4 stage `stage` (the servo chain up to it, formed exactly as dynamics_arm
+// forms its stage states) -> aggregates of that configuration -> agg[stage][slot][lane]; the wave of stage 3 also has all four joint
+// derivatives and writes the integrated joint state jn[6][lane] (same expressions as dynamics_arm: the joint trajectories of the staged and
+// the lane kernels are bit-identical).
+template <typename T, typename PT>
+__device__ __forceinline__ void arm_kin_stage(const PT& P, const ArmParams<T>& A, int stage, const T* th0, const T* td0, const T* cmd, float* agg, float* jn,
+                                              int lane) {
+  const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+  T th[3], td[3], a[3], accp[3], accv[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { th[k] = th0[k]; td[k] = td0[k]; a[k] = servo_(A, cmd[k], th[k], td[k]); accp[k] = td[k]; accv[k] = a[k]; }
+  for (int st = 0; st < stage; st++) {     // wave-uniform trip count
+    const T cn = st == 2 ? h : hh;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const T thn = fma_(cn, td[k], th0[k]), tdn = fma_(cn, a[k], td0[k]);
+      th[k] = thn; td[k] = tdn; a[k] = servo_(A, cmd[k], thn, tdn);
+      if (st < 2) { accp[k] = fma_(T(2), td[k], accp[k]); accv[k] = fma_(T(2), a[k], accv[k]); }
+    }
+  }
+  if (stage == 3) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      jn[k * 64 + lane] = float(fma_(h6, accp[k] + td[k], th0[k]));
+      jn[(3 + k) * 64 + lane] = float(fma_(h6, accv[k] + a[k], td0[k]));
+    }
+  }
+  T g[kAggSlots];
+  arm_kin_aggregates<T, PT>(P, A, th, td, a, g);
+  float* out = agg + size_t(stage) * kAggSlots * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < kAggSlots; q++) out[q * 64] = float(g[q]);
+}
+
+// 13 base derivatives from a stage's aggregates g.  y: position, velocity, quaternion, body rates.
+template <typename T, typename PT>
+__device__ __forceinline__ void arm_dyn_agg(const PT& P, const ArmParams<T>& A, const T* y, T F, V3<T> M, const T* g, T* d) {
+  const V3<T> om{y[10], y[11], y[12]};
+  const T n2 = fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9])));
+  const T in2 = rcp_(n2);
+  const T qw = y[6], qx = y[7], qy = y[8], qz = y[9];
+  const T two = T(2) * in2;
+  M3<T> Rq;
+  Rq.m[0] = fma_(-two, fma_(qy, qy, qz * qz), T(1)); Rq.m[1] = two * fma_(qx, qy, -(qw * qz)); Rq.m[2] = two * fma_(qx, qz, qw * qy);
+  Rq.m[3] = two * fma_(qx, qy, qw * qz); Rq.m[4] = fma_(-two, fma_(qx, qx, qz * qz), T(1)); Rq.m[5] = two * fma_(qy, qz, -(qw * qx));
+  Rq.m[6] = two * fma_(qx, qz, -(qw * qy)); Rq.m[7] = two * fma_(qy, qz, qw * qx); Rq.m[8] = fma_(-two, fma_(qx, qx, qy * qy), T(1));
+  const V3<T> gb{-P.g * Rq.m[2], -P.g * Rq.m[5], -P.g * Rq.m[8]};
+  const V3<T> S{g[AG_S], g[AG_S + 1], g[AG_S + 2]}, U{g[AG_U], g[AG_U + 1], g[AG_U + 2]}, Aa{g[AG_A], g[AG_A + 1], g[AG_A + 2]};
+  const V3<T> H{g[AG_H], g[AG_H + 1], g[AG_H + 2]}, Tn{g[AG_T], g[AG_T + 1], g[AG_T + 2]};
+  const V3<T> fb = cross(om, cross(om, S)) + T(2) * cross(om, U) + Aa;
+  const V3<T> IOw{dot3_(g[AG_IO], g[AG_IO + 1], g[AG_IO + 2], om.x, om.y, om.z), dot3_(g[AG_IO + 1], g[AG_IO + 3], g[AG_IO + 4], om.x, om.y, om.z),
+                  dot3_(g[AG_IO + 2], g[AG_IO + 4], g[AG_IO + 5], om.x, om.y, om.z)};
+  const V3<T> Gw{dot3_(g[AG_G], g[AG_G + 1], g[AG_G + 2], om.x, om.y, om.z), dot3_(g[AG_G + 3], g[AG_G + 4], g[AG_G + 5], om.x, om.y, om.z),
+                 dot3_(g[AG_G + 6], g[AG_G + 7], g[AG_G + 8], om.x, om.y, om.z)};
+  const V3<T> nb = cross(om, IOw) + Gw + cross(om, H) + Tn;
+  V3<T> f = A.mtot * gb - fb;
+  f.z += F;
+  const V3<T> n = M + cross(S, gb) - nb;
+  const V3<T> rhs = n - A.inv_mtot * cross(S, f);
+  const V3<T> wd{dot3_(g[AG_C], g[AG_C + 1], g[AG_C + 2], rhs.x, rhs.y, rhs.z), dot3_(g[AG_C + 1], g[AG_C + 3], g[AG_C + 4], rhs.x, rhs.y, rhs.z),
+                 dot3_(g[AG_C + 2], g[AG_C + 4], g[AG_C + 5], rhs.x, rhs.y, rhs.z)};
+  const V3<T> vd = mulT(Rq, A.inv_mtot * (f + cross(S, wd)));
+  d[0] = y[3]; d[1] = y[4]; d[2] = y[5];
+  d[3] = vd.x; d[4] = vd.y; d[5] = vd.z;
+  const T kq = fma_(T(-2), n2, T(2));
+  d[6] = fma_(T(0.5), fma_(om.x, qx, fma_(om.y, qy, om.z * qz)), kq * qw);
+  d[7] = fma_(T(-0.5), fma_(om.x, qw, fma_(om.y, qz, -(om.z * qy))), kq * qx);
+  d[8] = fma_(T(-0.5), fma_(om.y, qw, fma_(om.z, qx, -(om.x * qz))), kq * qy);
+  d[9] = fma_(T(-0.5), fma_(om.z, qw, fma_(om.x, qy, -(om.y * qx))), kq * qz);
+  d[10] = wd.x; d[11] = wd.y; d[12] = wd.z;
+}
+
+// LDS hand-over of step_kernel_armk: agg [4 stages][kAggSlots][64], jn [6][64] integrated joint state, words [12][64] reset words
+struct StagedXchg {
+  const float* agg; const float* jn; const uint32_t* words; int lane;
+  __device__ __forceinline__ void sync() const {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+constexpr int ARM_ROLE_STAGED = 5;
+
+// The main wave's control step of the staged kernel: mixer, ONE barrier (the stage waves have left their aggregates), RK4 on the 13 base
+// states with arm_dyn_agg, joints from the stage-3 wave.  One RK4 sub-step per control step.
+template <typename T, int NROT, int KW>
+__device__ __forceinline__ void dynamics_arm_staged(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act, const StagedXchg& x) {
+  const float Ff = (act[0] * P.mass_f) * P.g_f;
+  const T u0 = T(Ff), u1 = T(act[1] * P.mscale_f), u2 = T(act[2] * P.mscale_f), u3 = T(act[3] * P.mscale_f);
+  T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
+#pragma unroll
+  for (int r = 0; r < NROT; r++) {
+    T t = fma_(P.alloc[r][0], u0, fma_(P.alloc[r][1], u1, fma_(P.alloc[r][2], u2, P.alloc[r][3] * u3)));
+    t = clamp_(t, P.tmin[r], P.tmax[r]);
+    F = F + t; Mx = fma_(P.mixm[0][r], t, Mx); My = fma_(P.mixm[1][r], t, My); Mz = fma_(P.mixm[2][r], t, Mz);
+  }
+  const V3<T> M{Mx, My, Mz};
+  T y[13] = {e.px, e.py, e.pz, e.vx, e.vy, e.vz, e.qw, e.qx, e.qy, e.qz, e.wx, e.wy, e.wz};
+  const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
+  asm volatile("" : "+v"(F), "+v"(Mx), "+v"(My), "+v"(Mz));   // the mixer stays in front of the barrier
+  x.sync();
+  T k[13], acc[13], s[13], g[kAggSlots];
+  auto stage_agg = [&](int st) {
+#pragma unroll
+    for (int q = 0; q < kAggSlots; q++) g[q] = T(x.agg[(st * kAggSlots + q) * 64 + x.lane]);
+  };
+  stage_agg(0);
+  arm_dyn_agg<T>(P, A, y, F, M, g, k);
+#pragma unroll
+  for (int i = 0; i < 13; i++) { acc[i] = k[i]; s[i] = fma_(hh, k[i], y[i]); }
+  stage_agg(1);
+  arm_dyn_agg<T>(P, A, s, F, M, g, k);
+#pragma unroll
+  for (int i = 0; i < 13; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(hh, k[i], y[i]); }
+  stage_agg(2);
+  arm_dyn_agg<T>(P, A, s, F, M, g, k);
+#pragma unroll
+  for (int i = 0; i < 13; i++) { acc[i] = fma_(T(2), k[i], acc[i]); s[i] = fma_(h, k[i], y[i]); }
+  stage_agg(3);
+  arm_dyn_agg<T>(P, A, s, F, M, g, k);
+#pragma unroll
+  for (int i = 0; i < 13; i++) y[i] = fma_(h6, acc[i] + k[i], y[i]);
+  const T rn = rsqrt_(fma_(y[6], y[6], fma_(y[7], y[7], fma_(y[8], y[8], y[9] * y[9]))));
+  e.px = y[0]; e.py = y[1]; e.pz = y[2]; e.vx = y[3]; e.vy = y[4]; e.vz = y[5];
+  e.qw = y[6] * rn; e.qx = y[7] * rn; e.qy = y[8] * rn; e.qz = y[9] * rn;
+  e.wx = y[10]; e.wy = y[11]; e.wz = y[12];
+#pragma unroll
+  for (int j = 0; j < 3; j++) { e.th[j] = T(x.jn[j * 64 + x.lane]); e.thd[j] = T(x.jn[(3 + j) * 64 + x.lane]); }
+}
+
 }  // namespace amenv_dev

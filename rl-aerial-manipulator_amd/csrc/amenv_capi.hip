@@ -36,6 +36,7 @@ struct amenv {
   uint32_t tile_bytes = 0;
   int n_tiles = 0;
   int block = 64;
+  bool armk = false;               // hexacopter + z,x,x arm between the team kernel's range and the throughput regime: stage-wave kernel (step_kernel_armk)
   bool arm2w = false;              // hexacopter + z,x,x arm at small batches: two-wave step kernel (amenv_kernels.hpp)
   bool pwave = false;              // rigid vehicles at small batches: second wave per tile computes the reset RNG words (step_kernel_pw)
   bool team = false;               // lane-team kernel (16 lanes per env): fp32 z,x,x-arm vehicle in the latency regime (amenv_team.hpp)
@@ -49,6 +50,7 @@ struct amenv {
 };
 
 static thread_local std::string g_create_err;
+constexpr int kArmkAutoMax = 32768;   // AUTO: stage-wave arm kernel up to this batch (see amenv_create)
 
 namespace {
 
@@ -344,7 +346,7 @@ const char* validate(const amenv_config* c) {
         return "inertia and inv_inertia must be symmetric";
   // the blob holds whole 256-lane groups of tiles and padding lanes run unguarded: the workgroup size must divide 256
   if (c->block_size != 0 && c->block_size != 64 && c->block_size != 128 && c->block_size != 256) return "block_size must be 0, 64, 128 or 256";
-  if (c->step_kernel < AMENV_KERNEL_AUTO || c->step_kernel > AMENV_KERNEL_TEAM) return "unknown step_kernel";
+  if (c->step_kernel < AMENV_KERNEL_AUTO || c->step_kernel > AMENV_KERNEL_STAGED) return "unknown step_kernel";
   if (c->task.ee_task != AMENV_EE_TASK_BASE && c->task.ee_task != AMENV_EE_TASK_TOOL) return "unknown task.ee_task";
   return nullptr;
 }
@@ -373,6 +375,14 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
       if (timed) hipExtLaunchKernelGGL((step_kernel_team<NROT>), g2, b2s, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done,
                                        io.info, tl, C, TP);
       else hipLaunchKernelGGL((step_kernel_team<NROT>), g2, b2s, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, tl, C, TP);
+      return hipGetLastError();
+    }
+    if (T_steps == 0 && e.armk) {    // one tile per 320-thread workgroup: four stage waves + main wave
+      const dim3 g2(e.n_tiles), b2(320);
+      const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + (4 * kAggSlots + 6 + 12) * 64) * sizeof(float);   // obs rows | aggregates | joints | reset words
+      if (timed) hipExtLaunchKernelGGL((step_kernel_armk<T, NROT>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
+                                       io.done, io.info, tl, P, C, AA);
+      else hipLaunchKernelGGL((step_kernel_armk<T, NROT>), g2, b2, lds2, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C, AA);
       return hipGetLastError();
     }
     if (T_steps == 0 && e.arm2w) {   // one tile per 128-thread workgroup: main + helper wave
@@ -605,7 +615,19 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   }
   e->team_ok = cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes &&
                !is_v1(cfg) && cfg->task.num_waypoints == 1;
-  if (e->team) e->arm2w = false;
+  // stage-wave kernel (four RK4 stage waves + a main wave per 64-env tile): the fp32 6-rotor vehicle with the z,x,x arm, single-waypoint v2
+  // task, one RK4 sub-step
+  const bool armk_ok = e->team_ok && cfg->task.rk4_substeps == 1;
+  // measured on MI355X (tools/gpu_armk.sh, gpu_armk2.sh): 7.0 vs 7.8 us (two-wave kernel) at 6400 envs, 7.4 vs 8.1 at 12288, 9.0 vs 10.2 at 24576, 9.3 vs
+  // 10.6 at 32768; level from 36864 (10.6 vs 10.8) to 49152; a CU holds three of its workgroups (49 KB of LDS each), so above 49152 envs the
+  // launch takes a second round of workgroups: 14.4 vs 11.8 us at 53248
+  e->armk = armk_ok && (want == AMENV_KERNEL_AUTO ? (cfg->num_envs > 6144 && cfg->num_envs <= kArmkAutoMax) : want == AMENV_KERNEL_STAGED);
+  if (want == AMENV_KERNEL_STAGED && !e->armk) {
+    amenv_destroy(e);
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_STAGED is built for the fp32 6-rotor vehicle with the z,x,x arm, the single-waypoint v2 task "
+                "and rk4_substeps = 1");
+  }
+  if (e->team || e->armk) e->arm2w = false;
   if (e->team_ok) {
     if ((s = hipMalloc((void**)&e->pol_pack, size_t(kPolPackWords) * sizeof(uint32_t))) != hipSuccess) {
       std::string msg = std::string("amenv_create: policy pack: ") + hipGetErrorString(s);
@@ -626,6 +648,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
   else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6,v2+arm3> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave + episode-end helper wave)");
+  else if (e->armk) std::snprintf(buf, sizeof(buf), "step_kernel_armk<float,NROT=6> block=320 (4 RK4 stage waves + main wave per 64-env tile)");
   else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,

@@ -283,11 +283,12 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   const int K = KW == 1 ? 1 : P.K;
   if constexpr (NJ > 0) {
     if constexpr (ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_HELPER) dynamics_arm<T, NROT, KW, AxesZXX, ROLE, X>(P, AA.p, e, act, x);   // two-wave kernel: z,x,x arm only
+    else if constexpr (ROLE == ARM_ROLE_STAGED) dynamics_arm_staged<T, NROT, KW>(P, AA.p, e, act, x);                                   // stage-wave kernel: z,x,x arm only
     else if (AA.p.generic_axes) dynamics_arm<T, NROT, KW, AxesAny>(P, AA.p, e, act);   // wave-uniform: one of the two bodies runs
     else dynamics_arm<T, NROT, KW, AxesZXX>(P, AA.p, e, act);
   } else { dynamics<T, NROT, KW>(P, e, act[0], act[1], act[2], act[3]); }
   constexpr bool EE = NJ > 0;   // arm: forward kinematics of the post-step state feed the task point and the observation
-  if constexpr (EE) update_tool_offset<T, KW, ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_HELPER>(AA.p, e);
+  if constexpr (EE) update_tool_offset<T, KW, ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_HELPER || ROLE == ARM_ROLE_STAGED>(AA.p, e);
   const bool ee_task = EE && P.ee_task != 0;
   uint32_t bits;
   if constexpr (VAR == VAR_V1) { bits = task_step_v1<T, KW>(P, e, reward); } else { bits = task_step<T, KW, EE>(P, e, reward); }
@@ -305,7 +306,7 @@ __device__ __forceinline__ uint32_t step_lane(const HotParams<T, NROT>& P, const
   ep_len_out = 0; ep_ret_out = 0.0f;
   const bool ended = (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   const bool resets = ended && (P.flags & AMENV_FLAG_AUTO_RESET);
-  constexpr bool kWordsFromLds = ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_WORDS;
+  constexpr bool kWordsFromLds = ROLE == ARM_ROLE_MAIN || ROLE == ARM_ROLE_WORDS || ROLE == ARM_ROLE_STAGED;
   if constexpr (kWordsFromLds) x.sync();   // two-wave kernels: the helper has left every lane's 12 reset words in LDS (every step: unconditional barrier)
   if (__ballot(ended) != 0ull) {  // wave-uniform: the whole cold path is skipped by waves with no episode end
     uint32_t r[12];
@@ -762,6 +763,83 @@ __global__ __launch_bounds__(128) void step_kernel_arm2w(void* __restrict__ blob
   if (lane == 0 && blockIdx.x < kStampWaves)
     for (int kk = 0; kk < kStampSlots; kk++) io.stats[kStampBase + blockIdx.x * kStampSlots + kk] = stamps_[kk];
 #endif
+}
+
+// Stage-wave step kernel for the hexacopter + z,x,x arm between the lane-team kernel's range and the throughput regime (BASELINE
+// config 4: 32768 envs per GPU).  One tile of 64 environments per 320-thread workgroup:
+//   waves 0..3  one RK4 STAGE each: the joint servos do not feel the base, so the joint state of every stage follows from (th, thd, cmd)
+//               alone; the wave forms its stage's joint configuration and reduces everything the base dynamics needs from it to 36
+//               numbers per env (arm_kin_aggregates, ~2/3 of the step's arithmetic) -- all four stages side by side instead of in sequence;
+//               wave 3 also integrates the joints.  After the ONE barrier of the RK4, waves 0..2 compute the three Philox blocks a reset
+//               of their lanes would consume and leave them in LDS (second barrier), wave 3 is done.
+//   wave 4      everything else: mixer, RK4 on the 13 base states with arm_dyn_agg on the aggregates (~160 instructions per stage instead
+//               of ~960), forward kinematics, task step, observation, auto-reset, stores.
+// The critical path is one stage's kinematics + four short base stages instead of four full right-hand sides (10.4 us with the two-wave
+// kernel at 32768 envs).  Barriers: waves 0..2 and 4 execute two, wave 3 one (a finished wave no longer counts), all in uniform flow.
+template <typename T, int NROT>
+__global__ __launch_bounds__(320) void step_kernel_armk(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float4* __restrict__ actions,
+                                                        float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
+                                                        uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C,
+                                                        const ArmArg<T, 3> AA) {
+  static_assert(sizeof(T) == 4, "fp32 kernel");
+  constexpr int KW = 1, VAR = VAR_V2, NJ = 3;
+  constexpr int OD = ObsDim<VAR, NJ>::value, AD = kActDim + NJ;
+  const Head hd{blob, tile_bytes, n_envs};
+  const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging | [4][kAggSlots][64] aggregates | [6][64] joints | [12][64] reset words
+  float* agg = lds + 64 * OD;
+  float* jn = agg + 4 * kAggSlots * 64;
+  uint32_t* words = reinterpret_cast<uint32_t*>(jn + 6 * 64);
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);   // wave-uniform: 0..3 stage waves, 4 main
+  const int i = blockIdx.x * 64 + lane;
+  const bool active = i < hd.n;
+  char* tile = const_cast<char*>(tile_base(hd.blob, hd.tile_bytes, i));
+  const float* ap = reinterpret_cast<const float*>(io.actions) + size_t(min(i, hd.n - 1)) * AD;
+  if (role < 4) {
+    const Vec4<T> ja = *gptr<T>(tile, lane, 4 + KW), jr = *gptr<T>(tile, lane, 5 + KW);
+    const int32_t episode = iptr4(tile, lane)->w;
+    T cmd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) cmd[k] = T(__builtin_fmaf(ap[4 + k], AA.p.half[k], AA.p.mid[k]));
+    const T th0[3] = {ja.a, ja.b, ja.c}, td0[3] = {jr.a, jr.b, jr.c};
+    arm_kin_stage<T>(P, AA.p, role, th0, td0, cmd, agg, jn, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                     // aggregates (and the integrated joints) are in LDS
+    __builtin_amdgcn_sched_barrier(0);
+    if (role == 3) return;
+    const int64_t gid = C.gid0 + i;
+    uint32_t w[4];
+    philox4x32_10(C.seed_lo, C.seed_hi, uint32_t(uint64_t(gid)), uint32_t(uint64_t(gid) >> 32), uint32_t(episode), uint32_t(role), w);
+#pragma unroll
+    for (int k = 0; k < 4; k++) words[(4 * role + k) * 64 + lane] = w[k];
+    __syncthreads();                     // reset words published (pairs with the barrier in step_lane)
+    return;
+  }
+  Env<T, KW> e;
+  load_env<T, KW, 0>(1, tile, lane, e);    // the joints arrive integrated from wave 3
+  float act[AD];
+#pragma unroll
+  for (int j = 0; j < 4; j++) act[j] = ap[j];
+  act[4] = act[5] = act[6] = 0.0f;
+  const StagedXchg x{agg, jn, words, lane};
+  T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
+  uint32_t bits = step_lane<T, NROT, KW, VAR, NJ, ARM_ROLE_STAGED, StagedXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset,
+                                                                             ep_len, ep_ret, x);
+  const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
+  accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);
+  store_env_step<T, KW, NJ>(tile, lane, e);
+  if (was_reset) store_env_episode<T, KW>(1, tile, lane, e);
+  if (active) {
+    reinterpret_cast<T*>(io.reward)[i] = reward;
+    io.done[i] = is_done ? 1 : 0;
+    io.info[i] = bits;
+  }
+  stage_obs<OD>(lds + lane * OD, o);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();          // one wave stages and flushes: LDS accesses of a wave complete in order
+  const int row0 = blockIdx.x * 64;
+  flush_obs<OD>(lds, io.obs + size_t(row0) * OD, min(64, hd.n - row0), 64, lane);
 }
 
 // n_steps control steps per launch with open-loop actions [T][N][4]; per-step outputs [T][N]...

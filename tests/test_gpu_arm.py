@@ -65,15 +65,16 @@ def test_arm_dims_and_reset():
     env.close()
 
 
-# fp32 vs fp64 oracle: rounding level, far inside the 1e-5 gate; fp64 build: the logic gate; "team" = the lane-team kernel (16 lanes per env)
-@pytest.mark.parametrize("dtype,tol,kernel", [("f32", 2e-6, "lane"), ("f32", 2e-6, "helper"), ("f32", 3e-6, "team"), ("f64", 1e-12, "lane")])
+# fp32 vs fp64 oracle: rounding level, far inside the 1e-5 gate; fp64 build: the logic gate; "team" = the lane-team kernel (16 lanes per env),
+# "staged" = the stage-wave kernel (four RK4 stage waves + main wave per tile, base dynamics on joint-configuration aggregates)
+@pytest.mark.parametrize("dtype,tol,kernel", [("f32", 2e-6, "lane"), ("f32", 2e-6, "helper"), ("f32", 3e-6, "team"), ("f32", 3e-6, "staged"), ("f64", 1e-12, "lane")])
 def test_arm_closed_loop_vs_oracle(dtype, tol, kernel):
     """Teacher-forced per step (the oracle is re-seated on the GPU state each step), joints slewing, with resets."""
     import rl_aerial_manipulator_amd as amd
     n = 2048
     rng = np.random.RandomState(3)
     env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=9, dtype=dtype, max_episode_steps=120, kernel=kernel)
-    assert {"lane": "step_kernel<", "helper": "arm2w", "team": "step_kernel_team"}[kernel] in env.kernel_name
+    assert {"lane": "step_kernel<", "helper": "arm2w", "team": "step_kernel_team", "staged": "step_kernel_armk"}[kernel] in env.kernel_name
     orc = orc_arm(n, seed=9)
     orc.cfg.task.max_episode_steps = 120
     env.reset()
@@ -248,7 +249,7 @@ def test_arm_long_run_stays_finite():
     assert s["episodes"] > 10000 and s["episodes"] == s["terminated"] + s["truncated"]
 
 
-@pytest.mark.parametrize("kernel", ["lane", "team"])
+@pytest.mark.parametrize("kernel", ["lane", "team", "staged"])
 @pytest.mark.parametrize("ee_task", ["tool", "base"])
 def test_forward_kinematics_and_tool_point_task_vs_oracle(ee_task, kernel):
     """amenv_ee_position / obs[26:29] (forward kinematics) and the task point of the reward / reach test against the fp64 oracle, on
@@ -288,9 +289,11 @@ def test_forward_kinematics_and_tool_point_task_vs_oracle(ee_task, kernel):
     env.close()
 
 
-@pytest.mark.parametrize("n", [1, 3, 63, 65, 300, 4096])
-def test_team_kernel_tracks_the_lane_kernel(n):
-    """The lane-team kernel (AMENV_KERNEL_TEAM: 16 lanes per env, DPP exchanges) against the one-lane-per-env kernel on the same inputs:
+@pytest.mark.parametrize("n,kernel", [(1, "team"), (3, "team"), (63, "team"), (65, "team"), (300, "team"), (4096, "team"),
+                                      (1, "staged"), (65, "staged"), (300, "staged"), (8192, "staged")])
+def test_team_kernel_tracks_the_lane_kernel(n, kernel):
+    """The lane-team kernel (AMENV_KERNEL_TEAM: 16 lanes per env, DPP exchanges) and the stage-wave kernel (AMENV_KERNEL_STAGED: the RK4
+    stages' joint-configuration sums on four wavefronts, base dynamics on the aggregates) against the one-lane-per-env kernel on the same inputs:
     same resets (bit-exact: same Philox words, same fp32 arithmetic), same flags, states within fp32 rounding after every step
     (sums are associated differently, so not bit for bit), Monitor totals equal; ragged batches write nothing past row n."""
     import torch
@@ -302,8 +305,8 @@ def test_team_kernel_tracks_the_lane_kernel(n):
     acts[:, ::3, 0] = 0.15                      # a third of the envs sink: crashes and auto-resets inside the window
     acts = acts.clamp(-1, 2)
     lane = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=6, kernel="lane", max_episode_steps=90)
-    team = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=6, kernel="team", max_episode_steps=90)
-    assert "step_kernel_team" in team.kernel_name
+    team = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=6, kernel=kernel, max_episode_steps=90)
+    assert {"team": "step_kernel_team", "staged": "step_kernel_armk"}[kernel] in team.kernel_name
     o0 = lane.reset().clone(); o1 = team.reset().clone()
     assert torch.equal(o0, o1)
     guard = torch.full((n + 8, 29), 7.0, device="cuda")       # the team env writes its observations into rows [0, n) of this buffer only
@@ -364,11 +367,12 @@ def test_team_rollout_kernel_equals_team_steps():
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("n,kernel", [(300, "team"), (4096, "team"), (1000, "lane"), (20000, "auto")])
+@pytest.mark.parametrize("n,kernel", [(300, "team"), (4096, "team"), (1000, "lane"), (20000, "helper"), (20000, "auto")])
 def test_closed_loop_policy_rollout_kernel(n, kernel):
     """amenv_rollout_policy: T closed-loop steps in one launch (bf16-MFMA actor / critic, Gaussian sampling, clip, env step) in its two
     forms: 16 lanes per env (where amenv_step runs the lane-team kernel) and one lane per env (64 or 128 envs per workgroup).
-    The env part is checked EXACTLY by replaying the recorded (clipped) actions through amenv_step on a second env; the policy part against
+    The env part is checked EXACTLY by replaying the recorded (clipped) actions through amenv_step on a second env (the lane form carries the
+    arithmetic of the LANE / HELPER step kernels: where AUTO steps with the stage-wave kernel, the replay env is a LANE one); the policy part against
     the fp32 torch modules on the recorded observations (bf16 tolerance: means / values within 3e-2 of their scale); the samples
     statistically (z = (a - mean) / std ~ N(0, 1), log-probs consistent with the samples)."""
     import torch
@@ -381,8 +385,8 @@ def test_closed_loop_policy_rollout_kernel(n, kernel):
         for m in (pol.action_net,):                              # a less timid head than SB3's 0.01-gain init: means of O(0.3)
             m.weight.mul_(30.0)
     env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel, max_episode_steps=60)
-    ref = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel, max_episode_steps=60)
-    assert ("team" in env.kernel_name) == (kernel == "team")
+    ref = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="lane" if "armk" in env.kernel_name else kernel, max_episode_steps=60)
+    assert ("team" in env.kernel_name) == (kernel == "team") and ("armk" in env.kernel_name) == (kernel == "auto")
     o0 = env.reset().clone(); ref.reset()
     dev = env.device
     obs = torch.zeros(T + 1, n, 29, device=dev); acts = torch.zeros(T, n, 7, device=dev)

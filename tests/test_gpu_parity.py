@@ -341,7 +341,7 @@ def test_sharding_invariance(amd):
 @pytest.mark.parametrize("n", [4096, 32768, 262144])
 def test_full_size_properties(amd, n, vehicle):
     """BASELINE sizes (configs[1..3]: 4096 envs; 32768 per GPU; 262144 = the 8-GPU job's total), every vehicle, each with the kernel
-    AUTO selects at that size (helper-wave kernels up to 32768 / 65536 envs, the one-lane-per-env kernel above): size-independent
+    AUTO selects at that size (lane-team / stage-wave / helper-wave kernels by batch, the one-lane-per-env kernel above): size-independent
     invariants + determinism + Monitor totals."""
     torch = _torch()
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -355,7 +355,8 @@ def test_full_size_properties(amd, n, vehicle):
     runs = []
     for rep in range(2):
         env = amd.GpuWaypointEnv(n, seed=9, vehicle=vehicle, max_episode_steps=40)
-        assert ("team" in env.kernel_name) == (vehicle == "hexa_arm" and n <= 6144) and ("arm2w" in env.kernel_name) == (vehicle == "hexa_arm" and 6144 < n <= 65536)
+        assert ("team" in env.kernel_name) == (vehicle == "hexa_arm" and n <= 6144) and ("armk" in env.kernel_name) == (vehicle == "hexa_arm" and 6144 < n <= 32768)
+        assert ("arm2w" in env.kernel_name) == (vehicle == "hexa_arm" and 32768 < n <= 65536)
         assert ("_pw" in env.kernel_name) == (vehicle != "hexa_arm" and n <= 32768)
         env.reset()
         ndone = 0; ret = 0.0
@@ -679,7 +680,7 @@ def test_every_accepted_block_size_is_bit_identical(amd, vehicle, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("vehicle,kernel,n", [("hexa", "auto", 4096), ("quad", "auto", 1000), ("hexa", "lane", 1000), ("hexa_arm", "team", 4096),
-                                              ("hexa_arm", "team", 7000), ("hexa_arm", "helper", 1000), ("hexa_arm", "lane", 640)])
+                                              ("hexa_arm", "team", 7000), ("hexa_arm", "helper", 1000), ("hexa_arm", "lane", 640), ("hexa_arm", "staged", 1000)])
 def test_monitor_totals_and_episode_outputs_match_the_per_step_outputs(amd, vehicle, kernel, n):
     """The running totals (`amenv_stats_read`) and the per-episode outputs (ep_return, ep_len, terminal_obs) are written by helper
     wavefronts in the small-batch kernels (owned replicas, no atomics); whatever writes them, they must equal what the per-step outputs
