@@ -162,11 +162,15 @@ def test_pid_policy_kernel_equals_the_torch_restatement(vehicle):
     assert torch.allclose(hip.pstate[:, 0].cpu(), ref.t, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("vehicle,floor", [("quad", 0.8), ("hexa", 0.75)])
+@pytest.mark.parametrize("vehicle,floor", [("quad", 0.8), ("hexa", 0.75), ("hexa_arm", 0.8)])
 def test_pid_baseline_flies_the_gpu_env(vehicle, floor):
+    """Closed loop on the HIP env, everything resident on the GPU, two launches per control step (amenv_pid_policy, amenv_step).  With the
+    arm the position loop tracks the TOOL point (the task's point: forward kinematics in obs[26:29]) and the joints are held at home:
+    an action source independent of any trained policy that brings the tool point of the SDF-derived hexacopter + arm to the waypoint."""
     env = amd.GpuWaypointEnv(1024, vehicle=vehicle, seed=3)
     pol = PidWaypointPolicy.for_env(env)
     assert pol.pstate is not None and pol.pstate.dtype == torch.float32       # the fp32 HIP kernel is what flies
+    assert pol.tool_mode == (vehicle == "hexa_arm") and pol.act_dim == env.act_dim
     obs = env.reset()
     env.stats(reset=True)
     done = None
