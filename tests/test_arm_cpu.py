@@ -256,3 +256,66 @@ def test_tool_point_task_measures_from_the_end_effector():
     tool, base = outs[O.EE_TASK_TOOL]["info"], outs[O.EE_TASK_BASE]["info"]
     assert (tool[0] & O.INFO_SUCCESS) and not (tool[1] & O.INFO_SUCCESS)
     assert (base[1] & O.INFO_SUCCESS) and not (base[0] & O.INFO_SUCCESS)
+
+
+def _staged_aggregates(v, th, thd, thdd):
+    """The 30 joint-configuration sums of the stage-wave kernel (csrc/amenv_arm.hpp "Staged form"), component by component as the device
+    code forms them: S, U, Aa, I_O (incl. the base inertia), G, H, Tn."""
+    I0 = np.array(v.inertia).reshape(3, 3)
+    S, U, Aa, H, Tn = (np.zeros(3) for _ in range(5))
+    IO = I0.copy(); G = np.zeros((3, 3))
+    R = np.eye(3); p = np.zeros(3); pd = np.zeros(3); pdd = np.zeros(3); w = np.zeros(3); al = np.zeros(3)
+    for k in range(3):
+        o = np.array(v.joint_origin[3 * k:3 * k + 3]); ax = np.array(v.joint_axis[3 * k:3 * k + 3])
+        Ro = R @ o
+        pd = pd + np.cross(w, Ro); pdd = pdd + np.cross(al, Ro) + np.cross(w, np.cross(w, Ro)); p = p + Ro
+        z = R @ ax
+        al = al + z * thdd[k] + np.cross(w, z) * thd[k]; w = w + z * thd[k]; R = R @ rodrigues(ax, th[k])
+        Rc = R @ np.array(v.link_com[3 * k:3 * k + 3])
+        r = p + Rc; u = pd + np.cross(w, Rc); a_ = pdd + np.cross(al, Rc) + np.cross(w, np.cross(w, Rc))
+        J = R @ np.array(v.link_inertia[9 * k:9 * k + 9]).reshape(3, 3) @ R.T
+        m = v.link_mass[k]
+        xx, xy, xz, yy, yz, zz = J[0, 0], J[0, 1], J[0, 2], J[1, 1], J[1, 2], J[2, 2]
+        wx, wy, wz = w
+        E = np.array([[2 * (wz * xy - wy * xz), (wx * xz - wz * xx) + (wz * yy - wy * yz), (wy * xx - wx * xy) + (wz * yz - wy * zz)],
+                      [0.0, 2 * (wx * yz - wz * xy), (wy * xy - wx * yy) + (wx * zz - wz * xz)],
+                      [0.0, 0.0, 2 * (wy * xz - wx * yz)]])
+        E = E + np.triu(E, 1).T                                                   # D + D^T, D = J [w]x
+        S += m * r; U += m * u; Aa += m * a_
+        IO += J + m * ((r @ r) * np.eye(3) - np.outer(r, r))
+        G += 2 * m * ((u @ r) * np.eye(3) - np.outer(u, r)) - E
+        H += J @ w
+        Tn += m * np.cross(r, a_) + J @ al + np.cross(w, J @ w)
+    return S, U, Aa, IO, G, H, Tn
+
+
+def test_staged_form_of_the_arm_dynamics_is_the_same_right_hand_side():
+    """The stage-wave kernel (step_kernel_armk) evaluates the base dynamics on joint-configuration aggregates:
+        fb = w x (w x S) + 2 w x U + Aa,   nb = w x (I_O w) + G w + w x H + Tn
+    instead of summing per link with the base's angular velocity inside.  The identity is exact: same derivatives as the oracle's RHS
+    (which sums per link) to rounding, for random attitudes, rates, joint states, commands and wrenches."""
+    cfg = arm_cfg()
+    v = cfg.vehicle
+    rng = np.random.RandomState(0)
+    worst = 0.0
+    for _ in range(200):
+        s = np.zeros(19)
+        s[:6] = rng.normal(size=6); s[6:10] = rng.normal(size=4); s[6:10] /= np.linalg.norm(s[6:10])
+        s[10:13] = rng.normal(size=3) * 2; s[13:16] = rng.uniform(-1.5, 1.5, 3); s[16:19] = rng.normal(size=3) * 2
+        F = rng.uniform(10, 50); M = rng.normal(size=3); cmd = rng.uniform(-1.5, 1.5, 3)
+        d = O.arm_rhs(cfg, s, F, M, cmd)
+        om = s[10:13]
+        thdd = np.clip(v.joint_kp * (cmd - s[13:16]) - v.joint_kd * s[16:19], -v.joint_acc_max, v.joint_acc_max)
+        S, U, Aa, IO, G, H, Tn = _staged_aggregates(v, s[13:16], s[16:19], thdd)
+        Rq = rot_q(s[6:10])
+        gb = -v.g * Rq[:, 2]
+        fb = np.cross(om, np.cross(om, S)) + 2 * np.cross(om, U) + Aa
+        nb = np.cross(om, IO @ om) + G @ om + np.cross(om, H) + Tn
+        f = v.mass * gb - fb; f[2] += F
+        n = M + np.cross(S, gb) - nb
+        Ic = IO - ((S @ S) * np.eye(3) - np.outer(S, S)) / v.mass
+        wd = np.linalg.solve(Ic, n - np.cross(S, f) / v.mass)
+        vd = Rq.T @ ((f + np.cross(S, wd)) / v.mass)
+        worst = max(worst, np.abs(vd - d[3:6]).max() / max(1.0, np.abs(d[3:6]).max()), np.abs(wd - d[10:13]).max() / max(1.0, np.abs(d[10:13]).max()),
+                    np.abs(thdd - d[16:19]).max())
+    assert worst < 1e-12, worst
