@@ -294,6 +294,18 @@ TeamParams make_team(const amenv& e) {
     P.o1[j] = float(v.joint_origin[3 + j]); P.o2[j] = float(v.joint_origin[6 + j]); P.tool[j] = float(v.tool_offset[j]);
     P.ee_home[j] = float(v.joint_origin[j] + v.joint_origin[3 + j] + v.joint_origin[6 + j] + v.tool_offset[j]);
   }
+  for (int k = 0; k < 3; k++) {
+    P.lm[k] = float(v.link_mass[k]);
+    for (int j = 0; j < 3; j++) P.lcm[k][j] = float(v.link_com[3 * k + j]);
+    const double* I = &v.link_inertia[9 * k];
+    const double six[6] = {I[0], I[1], I[2], I[4], I[5], I[8]};
+    for (int j = 0; j < 6; j++) P.li[k][j] = float(six[j]);
+  }
+  {
+    const double* I = v.inertia;
+    const double six[6] = {I[0], I[1], I[2], I[4], I[5], I[8]};
+    for (int j = 0; j < 6; j++) P.I0[j] = float(six[j]);
+  }
   P.kp = float(v.joint_kp); P.kd = float(v.joint_kd); P.amax = float(v.joint_acc_max);
   P.mtot = float(v.mass); P.inv_mtot = float(1.0 / v.mass); P.g = float(v.g);
   const int ns = c.task.rk4_substeps > 0 ? c.task.rk4_substeps : 1;

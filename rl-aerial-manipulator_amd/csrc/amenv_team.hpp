@@ -81,6 +81,7 @@ struct TeamParams {          // wave-uniform (SGPRs)
   float kp, kd, amax, mtot, inv_mtot, g, h;
   float tmin[6], tmax[6];
   float ee_home[3];
+  float lm[3], lcm[3][3], li[3][6], I0[6];   // stage-parallel form: link masses, CoMs (link frame), inertias (xx xy xz yy yz zz), base inertia
   int32_t substeps, max_steps, counter_limit, ee_task, K;   // K = 1 (the task code reads it)
   uint32_t flags;
   const float4* consts;      // [(kTeamConsts + 3) / 4][16] float4: constants 4k..4k+3 of lane column l at [k][l]
@@ -227,6 +228,127 @@ __device__ __forceinline__ TeamDeriv team_dyn(const TeamParams& P, const float* 
   dq = fma_(c[TC_SR] * bc<2>(W), qp<3, 2, 1, 0>(Q), dq);
   d.V = vd; d.Q = dq; d.W = wd;
   return d;
+}
+
+// ---- Stage-parallel form (round 2) -------------------------------------------------------------------------------------------------
+// The body-parallel form above spends the four quads of a row on the four BODIES and walks the four RK4 stages' joint configurations
+// one after the other (4 x team_kin), with masked chain steps (every quad executes all joint advances) and two DPP adds per summed
+// register and stage.  With the aggregated form of the base dynamics (amenv_arm.hpp "Staged form": fb = w x (w x S) + 2 w x U + Aa,
+// nb = w x (I_O w) + G w + w x H + Tn) a stage's joint configuration reaches the base dynamics as 14 registers that do not depend on
+// the base's rates -- so the four quads take the four STAGES instead: quad s forms stage s's joint state and runs the chain and the
+// three links for it, unmasked, all four stages at once (~450 instructions instead of 4 x ~200); then the serial part: every quad
+// evaluates team_dyn_agg with ITS OWN aggregates on the common stage state, stage s's derivative is the one quad s computed, picked and
+// broadcast with a multiply by the quad's 0 / 1 selector and the bit-identical row sum (x + 0 + 0 + 0 is exact in every quad).
+struct TeamAgg {
+  X3 S, U, H;        // sum m r, sum m u, sum J w_k (component per lane, rotations cached)
+  float Aa, Tn;      // sum m a, sum m r x a + J al + w_k x (J w_k)
+  TM IO, G, C;       // I_O, G (row per lane), adjugate of the composite inertia I_c divided by its determinant
+};
+
+__device__ __forceinline__ TeamAgg team_kin_stage(const TeamParams& P, const float* c, float TH, float THD, float thdd) {
+  const float e0 = c[TC_E0], e1 = c[TC_E1], e2 = c[TC_E2];
+  float S = 0.0f, U = 0.0f, Aa = 0.0f, H = 0.0f, Tn = 0.0f;
+  TM IO{fma_(e0, P.I0[0], fma_(e1, P.I0[1], e2 * P.I0[2])), fma_(e0, P.I0[1], fma_(e1, P.I0[3], e2 * P.I0[4])),
+        fma_(e0, P.I0[2], fma_(e1, P.I0[4], e2 * P.I0[5]))};          // base body: r = 0, J = I0
+  TM G{0.0f, 0.0f, 0.0f};
+  TM R;
+  float p, pd = 0.0f, pdd = 0.0f, w, al;
+  {   // joint 1 about z at the start of the chain
+    float s, co;
+    sincos_t(bc<0>(TH), s, co);
+    p = c[TC_O0];
+    w = bc<0>(THD) * e2; al = bc<0>(thdd) * e2;
+    R.c0 = fma_(co, e0, s * e1); R.c1 = fma_(co, e1, -(s * e0)); R.c2 = e2;
+  }
+  auto link = [&](int k) {   // link k behind the joints advanced so far: CoM motion relative to the body frame, inertia in body axes, sums
+    const float m = P.lm[k];
+    const float Rc = fma_(R.c0, P.lcm[k][0], fma_(R.c1, P.lcm[k][1], R.c2 * P.lcm[k][2]));
+    const X3 xw = x3(w), xRc = x3(Rc);
+    const float wRc = cross(xw, xRc);
+    const float r = p + Rc, u = pd + wRc;
+    const float a_ = pdd + cross_c(xw, wRc) - cross_c(xRc, al);
+    const float RI0 = fma_(R.c0, P.li[k][0], fma_(R.c1, P.li[k][1], R.c2 * P.li[k][2]));
+    const float RI1 = fma_(R.c0, P.li[k][1], fma_(R.c1, P.li[k][3], R.c2 * P.li[k][4]));
+    const float RI2 = fma_(R.c0, P.li[k][2], fma_(R.c1, P.li[k][4], R.c2 * P.li[k][5]));
+    const TM J{fma_(RI0, bc<0>(R.c0), fma_(RI1, bc<0>(R.c1), RI2 * bc<0>(R.c2))), fma_(RI0, bc<1>(R.c0), fma_(RI1, bc<1>(R.c1), RI2 * bc<1>(R.c2))),
+               fma_(RI0, bc<2>(R.c0), fma_(RI1, bc<2>(R.c1), RI2 * bc<2>(R.c2)))};
+    S = fma_(m, r, S); U = fma_(m, u, U); Aa = fma_(m, a_, Aa);
+    const float mr2 = m * dot3(r, r), mr = m * r;
+    IO.c0 += fma_(-mr, bc<0>(r), fma_(mr2, e0, J.c0));
+    IO.c1 += fma_(-mr, bc<1>(r), fma_(mr2, e1, J.c1));
+    IO.c2 += fma_(-mr, bc<2>(r), fma_(mr2, e2, J.c2));
+    // G += 2 m ((u . r) 1 - u r^T) - (D + D^T), D = J [w]x: column j of D is J (w x e_j), column j of D^T is -w x (column j of J)
+    const float m2 = m + m, d = m2 * dot3(u, r), mu = m2 * u;
+    const float wx = bc<0>(w), wy = bc<1>(w), wz = bc<2>(w);
+    G.c0 += fma_(-mu, bc<0>(r), d * e0) - (fma_(wz, J.c1, -(wy * J.c2)) - cross_c(xw, J.c0));
+    G.c1 += fma_(-mu, bc<1>(r), d * e1) - (fma_(wx, J.c2, -(wz * J.c0)) - cross_c(xw, J.c1));
+    G.c2 += fma_(-mu, bc<2>(r), d * e2) - (fma_(wy, J.c0, -(wx * J.c1)) - cross_c(xw, J.c2));
+    const float Jw = matvec(J, w);
+    H += Jw;
+    Tn += fma_(m, cross_c(x3(r), a_), matvec(J, al)) + cross_c(xw, Jw);
+  };
+  auto advance_x = [&](float th, float td, float tdd, const float* o) {   // across a joint about its frame's x axis (column 0 of R)
+    float s, co;
+    sincos_t(th, s, co);
+    const float Ro = fma_(R.c0, o[0], fma_(R.c1, o[1], R.c2 * o[2]));
+    const X3 xRo = x3(Ro), xw = x3(w);
+    const float wRo = cross(xw, xRo);
+    pd += wRo;
+    pdd += cross_c(xw, wRo) - cross_c(xRo, al);      // al x Ro + w x (w x Ro)
+    p += Ro;
+    const float z = R.c0;
+    const float wz = cross_c(xw, z);
+    al = fma_(td, wz, fma_(tdd, z, al));
+    w = fma_(td, z, w);
+    rotate_cols<0>(R, s, co);
+  };
+  link(0);
+  advance_x(bc<1>(TH), bc<1>(THD), bc<1>(thdd), P.o1);
+  link(1);
+  advance_x(bc<2>(TH), bc<2>(THD), bc<2>(thdd), P.o2);
+  link(2);
+  TeamAgg k;
+  k.S = x3(S); k.U = x3(U); k.H = x3(H); k.Aa = Aa; k.Tn = Tn; k.IO = IO; k.G = G;
+  // composite inertia about the system CoM, I_c = I_O - (|S|^2 1 - S S^T) / mtot, its adjugate (columns = cross products of columns) / det
+  const float im = P.inv_mtot;
+  const float imS2 = im * dot3(S, S), imS = im * S;
+  const X3 x0 = x3(fma_(imS, bc<0>(S), fma_(-imS2, e0, IO.c0)));
+  const X3 x1 = x3(fma_(imS, bc<1>(S), fma_(-imS2, e1, IO.c1)));
+  const X3 x2 = x3(fma_(imS, bc<2>(S), fma_(-imS2, e2, IO.c2)));
+  const TM A{cross(x1, x2), cross(x2, x0), cross(x0, x1)};
+  const float idet = rcp_(dot3(x0.v, A.c0));
+  k.C = TM{idet * A.c0, idet * A.c1, idet * A.c2};
+  return k;
+}
+
+__device__ __forceinline__ TeamDeriv team_dyn_agg(const TeamParams& P, const float* c, const TeamAgg& k, float Q, float W, float F, float Mv) {
+  TeamDeriv d;
+  const float e2 = c[TC_E2], im = P.inv_mtot;
+  const float n2 = sum4(Q * Q);
+  const float two_in2 = 2.0f * rcp_(n2);
+  const X3 qv{qp<1, 2, 3, 3>(Q), qp<2, 3, 1, 3>(Q), qp<3, 1, 2, 3>(Q)};
+  const float qw = bc<0>(Q);
+  const X3 om = x3(W);
+  const X3 gv{c[TC_GV], c[TC_GV1], c[TC_GV2]};
+  const float gb = fma_(two_in2, cross_c(qv, fma_(qw, gv.v, cross(qv, gv))), gv.v);
+  const float fb = fma_(2.0f, cross(om, k.U), cross_c(om, cross(om, k.S))) + k.Aa;
+  const float nb = (cross_c(om, matvec(k.IO, W)) + matvec(k.G, W)) + (cross(om, k.H) + k.Tn);
+  const float f = fma_(F, e2, fma_(P.mtot, gb, -fb));
+  const float n = Mv + cross_c(k.S, gb) - nb;
+  const float rhs = fma_(-im, cross_c(k.S, f), n);
+  const float wd = matvec(k.C, rhs);
+  const float Aacc = im * (f + cross_c(k.S, wd));
+  const float vd = fma_(two_in2, cross_c(qv, fma_(-qw, Aacc, cross_c(qv, Aacc))), Aacc);
+  float dq = fma_(-2.0f, n2, 2.0f) * Q;
+  dq = fma_(c[TC_SP] * bc<0>(W), qp<1, 0, 3, 2>(Q), dq);
+  dq = fma_(c[TC_SQ] * bc<1>(W), qp<2, 3, 0, 1>(Q), dq);
+  dq = fma_(c[TC_SR] * bc<2>(W), qp<3, 2, 1, 0>(Q), dq);
+  d.V = vd; d.Q = dq; d.W = wd;
+  return d;
+}
+// the derivative quad `sel` (1 in that quad, 0 elsewhere) computed, in all four quads of the row, bit-identical
+__device__ __forceinline__ TeamDeriv team_pick(const TeamDeriv& d, float sel) {
+  return TeamDeriv{sum_bodies(d.V * sel), sum_bodies(d.Q * sel), sum_bodies(d.W * sel)};
 }
 
 // tool point relative to the body origin, world axes, of a (unit-quaternion) state: chain positions in the link-3 quad, summed over the row
@@ -388,6 +510,7 @@ __device__ __forceinline__ TeamOut team_advance(const TeamParams& P, const ColdP
     const float TH2 = fma_(hh, y.THD, y.TH), THD2 = fma_(hh, a1, y.THD), a2 = joint_accel(P, cmd, TH2, THD2);
     const float TH3 = fma_(hh, THD2, y.TH), THD3 = fma_(hh, a2, y.THD), a3 = joint_accel(P, cmd, TH3, THD3);
     const float TH4 = fma_(h, THD3, y.TH), THD4 = fma_(h, a3, y.THD), a4 = joint_accel(P, cmd, TH4, THD4);
+#ifdef AMENV_TEAM_BODY_PARALLEL   // A/B build (tools/build_variant.py): the body-parallel form
     const TeamKin k1 = team_kin(P, c, y.TH, y.THD, a1), k2 = team_kin(P, c, TH2, THD2, a2), k3 = team_kin(P, c, TH3, THD3, a3),
                   k4 = team_kin(P, c, TH4, THD4, a4);
     TeamDeriv d = team_dyn(P, c, k1, y.Q, y.W, F, Mv);
@@ -400,6 +523,23 @@ __device__ __forceinline__ TeamOut team_advance(const TeamParams& P, const ColdP
     aP = fma_(2.0f, sV, aP); aV = fma_(2.0f, d.V, aV); aQ = fma_(2.0f, d.Q, aQ); aW = fma_(2.0f, d.W, aW);
     sV = fma_(h, d.V, y.V); sQ = fma_(h, d.Q, y.Q); sW = fma_(h, d.W, y.W);
     d = team_dyn(P, c, k4, sQ, sW, F, Mv);
+#else
+    // quad s of the row takes RK4 stage s: its joint state, then the aggregates of that joint configuration (all four stages at once)
+    const float s0 = L.q0 ? 1.0f : 0.0f, s1 = L.q1 ? 1.0f : 0.0f, s2 = L.q2 ? 1.0f : 0.0f, s3 = (L.q0 || L.q1 || L.q2) ? 0.0f : 1.0f;
+    const float THs = L.q0 ? y.TH : (L.q1 ? TH2 : (L.q2 ? TH3 : TH4)), THDs = L.q0 ? y.THD : (L.q1 ? THD2 : (L.q2 ? THD3 : THD4));
+    const float as = L.q0 ? a1 : (L.q1 ? a2 : (L.q2 ? a3 : a4));
+    const TeamAgg k = team_kin_stage(P, c, THs, THDs, as);
+    TeamDeriv d = team_pick(team_dyn_agg(P, c, k, y.Q, y.W, F, Mv), s0);
+    float aP = y.V, aV = d.V, aQ = d.Q, aW = d.W;                       // acc = k1
+    float sV = fma_(hh, d.V, y.V), sQ = fma_(hh, d.Q, y.Q), sW = fma_(hh, d.W, y.W);
+    d = team_pick(team_dyn_agg(P, c, k, sQ, sW, F, Mv), s1);
+    aP = fma_(2.0f, sV, aP); aV = fma_(2.0f, d.V, aV); aQ = fma_(2.0f, d.Q, aQ); aW = fma_(2.0f, d.W, aW);
+    sV = fma_(hh, d.V, y.V); sQ = fma_(hh, d.Q, y.Q); sW = fma_(hh, d.W, y.W);
+    d = team_pick(team_dyn_agg(P, c, k, sQ, sW, F, Mv), s2);
+    aP = fma_(2.0f, sV, aP); aV = fma_(2.0f, d.V, aV); aQ = fma_(2.0f, d.Q, aQ); aW = fma_(2.0f, d.W, aW);
+    sV = fma_(h, d.V, y.V); sQ = fma_(h, d.Q, y.Q); sW = fma_(h, d.W, y.W);
+    d = team_pick(team_dyn_agg(P, c, k, sQ, sW, F, Mv), s3);
+#endif
     y.P = fma_(h6, aP + sV, y.P); y.V = fma_(h6, aV + d.V, y.V); y.Q = fma_(h6, aQ + d.Q, y.Q); y.W = fma_(h6, aW + d.W, y.W);
     const float nTH = fma_(h6, fma_(2.0f, THD3, fma_(2.0f, THD2, y.THD)) + THD4, y.TH);
     y.THD = fma_(h6, fma_(2.0f, a3, fma_(2.0f, a2, a1)) + a4, y.THD);
