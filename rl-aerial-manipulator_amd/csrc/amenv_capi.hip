@@ -16,6 +16,7 @@
 
 #include "amenv_kernels.hpp"
 #include "amenv_team.hpp"
+#include "amenv_quad.hpp"
 #include "amenv_team_policy.hpp"
 #include "amenv_lane_policy.hpp"
 #include "amenv_obsnorm.hpp"
@@ -36,6 +37,7 @@ struct amenv {
   uint32_t tile_bytes = 0;
   int n_tiles = 0;
   int block = 64;
+  bool quadk = false;              // rigid vehicles in the latency regime: lane-quad kernel (4 lanes per env, amenv_quad.hpp)
   bool armk = false;               // hexacopter + z,x,x arm between the team kernel's range and the throughput regime: stage-wave kernel (step_kernel_armk)
   bool arm2w = false;              // hexacopter + z,x,x arm at small batches: two-wave step kernel (amenv_kernels.hpp)
   bool pwave = false;              // rigid vehicles at small batches: second wave per tile computes the reset RNG words (step_kernel_pw)
@@ -50,6 +52,7 @@ struct amenv {
 };
 
 static thread_local std::string g_create_err;
+constexpr int kQuadAutoMax = 16384;   // AUTO: lane-quad rigid kernel up to this batch (see amenv_create)
 constexpr int kArmkAutoMax = 32768;   // AUTO: stage-wave arm kernel up to this batch (see amenv_create)
 
 namespace {
@@ -318,6 +321,23 @@ TeamParams make_team(const amenv& e) {
   return P;
 }
 
+QuadParams make_quad(const amenv& e) {
+  const amenv_config& c = e.cfg;
+  const amenv_vehicle& v = c.vehicle;
+  QuadParams P;
+  std::memset(&P, 0, sizeof(P));
+  const int six[6] = {0, 1, 2, 4, 5, 8};
+  for (int j = 0; j < 6; j++) { P.I[j] = float(v.inertia[six[j]]); P.Iinv[j] = float(v.inv_inertia[six[j]]); }
+  P.inv_mass = float(1.0 / v.mass);
+  const int ns = c.task.rk4_substeps > 0 ? c.task.rk4_substeps : 1;
+  P.h = float(c.task.dt / ns); P.substeps = ns;
+  for (int r = 0; r < 6 && r < v.n_rotors; r++) { P.tmin[r] = float(v.t_min[r]); P.tmax[r] = float(v.t_max[r]); }
+  P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit; P.flags = c.flags;
+  P.ee_task = 0; P.K = 1;
+  P.consts = reinterpret_cast<const float4*>(e.team_consts);
+  return P;
+}
+
 ColdParams make_cold(const amenv& e) {
   const amenv_config& c = e.cfg;
   ColdParams C;
@@ -403,6 +423,20 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
       if (timed) hipExtLaunchKernelGGL((step_kernel_arm2w<T, NROT>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
                                        io.done, io.info, tl, P, C, AA);
       else hipLaunchKernelGGL((step_kernel_arm2w<T, NROT>), g2, b2, lds2, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C, AA);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (NJ == 0 && sizeof(T) == 4 && KW == 1 && VAR == VAR_V2 && (NROT == 4 || NROT == 6)) {
+    if (e.quadk) {   // 4 lanes per env, 16 envs per workgroup (step: main wave + episode-end helper wave; rollout: one wave)
+      const dim3 g2(e.n_tiles * 4), b1(64), b2(128);
+      const QuadParams QP = make_quad(e);
+      if (T_steps > 0) {
+        hipLaunchKernelGGL((rollout_kernel_quad<NROT>), g2, b1, 0, s, e.blob, tb, n, io.actions, io.obs, static_cast<float*>(io.reward), io.done, io.info, T_steps, tl, C, QP);
+        return hipGetLastError();
+      }
+      if (timed) hipExtLaunchKernelGGL((step_kernel_quad<NROT>), g2, b2, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, static_cast<float*>(io.reward), io.done,
+                                       io.info, tl, C, QP);
+      else hipLaunchKernelGGL((step_kernel_quad<NROT>), g2, b2, 0, s, e.blob, tb, n, io.actions, io.obs, static_cast<float*>(io.reward), io.done, io.info, tl, C, QP);
       return hipGetLastError();
     }
   }
@@ -621,9 +655,15 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // episode-end helper wave: above 4096 envs the SIMDs hold more than two waves) -> AUTO up to 6144 envs
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes)
     e->team = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 6144 : want == AMENV_KERNEL_TEAM;
-  if (want == AMENV_KERNEL_TEAM && !e->team) {
+  // lane-quad kernel (4 lanes per env) for the rigid vehicles: fp32, 4 or 6 rotors, single-waypoint v2 task, default workgroup size
+  const bool quad_ok = cfg->vehicle.n_joints == 0 && cfg->dtype == AMENV_F32 && (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) && !is_v1(cfg) &&
+                       cfg->task.num_waypoints == 1 && cfg->block_size == 0;
+  e->quadk = quad_ok && (want == AMENV_KERNEL_AUTO ? cfg->num_envs <= kQuadAutoMax : want == AMENV_KERNEL_TEAM);
+  if (e->quadk) e->pwave = false;
+  if (want == AMENV_KERNEL_TEAM && !e->team && !e->quadk) {
     amenv_destroy(e);
-    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is built for the fp32 6-rotor vehicle with the z,x,x arm");
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is built for the fp32 6-rotor vehicle with the z,x,x arm (16 lanes per env) and for "
+                "fp32 rigid vehicles with 4 or 6 rotors, the single-waypoint v2 task and block_size = 0 (4 lanes per env)");
   }
   e->team_ok = cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes &&
                !is_v1(cfg) && cfg->task.num_waypoints == 1;
@@ -640,6 +680,15 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                 "and rk4_substeps = 1");
   }
   if (e->team || e->armk) e->arm2w = false;
+  if (e->quadk) {
+    const std::vector<float> tc = team_const_table(*cfg);
+    if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(float))) != hipSuccess ||
+        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
+      std::string msg = std::string("amenv_create: quad constants: ") + hipGetErrorString(s);
+      amenv_destroy(e);
+      return fail(nullptr, AMENV_ERR_ALLOC, msg);
+    }
+  }
   if (e->team_ok) {
     if ((s = hipMalloc((void**)&e->pol_pack, size_t(kPolPackWords) * sizeof(uint32_t))) != hipSuccess) {
       std::string msg = std::string("amenv_create: policy pack: ") + hipGetErrorString(s);
@@ -659,6 +708,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                               cfg->dtype == AMENV_F64 ? "double" : "float",
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
+  else if (e->quadk) std::snprintf(buf, sizeof(buf), "step_kernel_quad<NROT=%d,v2> (4 lanes per env, 16 envs per wave + episode-end helper wave)", cfg->vehicle.n_rotors);
   else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6,v2+arm3> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave + episode-end helper wave)");
   else if (e->armk) std::snprintf(buf, sizeof(buf), "step_kernel_armk<float,NROT=6> block=320 (4 RK4 stage waves + main wave per 64-env tile)");
   else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");

@@ -17,12 +17,14 @@ bash tools/pmc_sq.sh hexa_arm team > /dev/null 2>&1; cp gpurun_out/pmc_sq_hexa_a
 bash tools/pmc_sq.sh hexa_arm helper > /dev/null 2>&1; cp gpurun_out/pmc_sq_hexa_arm_helper.txt $O/pmc_sq_step_kernel_arm2w_4096.txt
 bash tools/pmc_sq.sh hexa auto > /dev/null 2>&1; cp gpurun_out/pmc_sq_hexa_auto.txt $O/pmc_sq_step_kernel_pw_4096.txt
 bash tools/pmc_sq.sh hexa_arm auto 1048576 > /dev/null 2>&1; cp gpurun_out/pmc_sq_hexa_arm_auto_1048576.txt $O/pmc_sq_step_kernel_arm_1048576.txt
+bash tools/pmc_sq.sh hexa_arm staged 32768 > /dev/null 2>&1; cp gpurun_out/pmc_sq_hexa_arm_staged_32768.txt $O/pmc_sq_step_kernel_armk_32768.txt
 echo "sq done"
 AMENV_LIB=$R/tools/micro/libamenv_stamps.so python tools/stamp_team.py > $O/stamps_team_4096.txt 2>/dev/null
 AMENV_LIB=$R/tools/micro/libamenv_stamps.so python tools/stamp_pw.py --vehicle hexa > $O/stamps_pw_hexa_4096.txt 2>/dev/null
 AMENV_LIB=$R/tools/micro/libamenv_stamps.so python tools/launch_floor.py --envs 4096 > $O/launch_floor.txt 2>/dev/null
 for V in hexa quad hexa_arm; do python tools/reset_cost.py --vehicle $V 2>/dev/null; done > $O/reset_cost.txt
 (bash tools/gpu_cross.sh; CROSS_SIZES="4096 4608 5120 6144" bash tools/gpu_cross.sh) > $O/crossover_team_vs_arm2w.txt 2>&1
+SKIP_TESTS=1 bash tools/gpu_armk.sh > /dev/null 2>&1; cat gpurun_out/armk/sweep.txt > $O/crossover_stage_wave_kernel.txt
 echo "stamps done"
 bash tools/gpu_r02_g.sh > $O/sweep.txt 2>&1
 cat gpurun_out/r02g/vecenv_quad.json gpurun_out/r02g/vecenv_arm.json > $O/vecenv_rate.json
