@@ -56,7 +56,8 @@ extern "C" {
 #define AMENV_KERNEL_AUTO 0
 #define AMENV_KERNEL_LANE 1   /* one lane per env, one wavefront per 64-env tile                                      */
 #define AMENV_KERNEL_HELPER 2 /* LANE + helper wavefronts per tile (reset RNG words, observation rows, arm link 3)     */
-#define AMENV_KERNEL_TEAM 3   /* a team of 16 lanes (one DPP row) per env: 4 bodies x 4 vector components across lanes */
+#define AMENV_KERNEL_TEAM 3   /* arm vehicle: a team of 16 lanes (one DPP row) per env, AUTO up to 6144 envs; rigid vehicles: 4 lanes (one
+                                 DPP quad) per env, opt-in only (measured no faster than HELPER)                          */
 #define AMENV_KERNEL_STAGED 4 /* arm vehicle: the four RK4 stages' joint-configuration work on four wavefronts side by side,
                                  the base dynamics on their 36-number aggregates on a fifth (not bit-identical to LANE)  */
 
@@ -368,11 +369,11 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
  * PPO.train(); Adam with eps 1e-5, v2/rl_train.py:38 through SB3's defaults).  exp_avg / exp_avg_sq / step: torch.optim.Adam's state for
  * that parameter (step: ONE f32 on the device, as torch keeps it with capturable=True; incremented here).  hyper6 (device): lr, beta1,
  * beta2, eps, max_grad_norm (<= 0: no clipping), grad_scale (multiplies the gradient first: 1 / world size after a sum all-reduce).
- * flat_grad is left scaled and clipped, grad_norm_out (may be NULL) receives the norm before clipping.  The norm is complete before any
- * gradient element is overwritten (one workgroup with a barrier up to 65,536 parameters, two launches above).  word: one device word of
- * scratch (the large-buffer path passes the norm through it; contents undefined afterwards). */
-int amenv_ppo_adam_step(float* flat_params, float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6,
-                        float* grad_norm_out, uint32_t* word, void* stream);
+ * flat_grad is READ-ONLY (the clipped gradient is applied, not stored: every workgroup of the launch takes the norm of the whole buffer
+ * as it was on entry), grad_norm_out (may be NULL) receives the norm before clipping.  ticket: one zero-initialised device word the
+ * kernel uses and leaves zero. */
+int amenv_ppo_adam_step(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6,
+                        float* grad_norm_out, uint32_t* ticket, void* stream);
 
 /* ---- PID + minimum-snap baseline controller ------------------------------------------------------------
  * The reference's hand-tuned controller, `v2/PID Controller/{pid_controller,trajGen3D,runsim}.py`, for N vehicles per launch on caller-owned

@@ -52,7 +52,6 @@ struct amenv {
 };
 
 static thread_local std::string g_create_err;
-constexpr int kQuadAutoMax = 16384;   // AUTO: lane-quad rigid kernel up to this batch (see amenv_create)
 constexpr int kArmkAutoMax = 32768;   // AUTO: stage-wave arm kernel up to this batch (see amenv_create)
 
 namespace {
@@ -658,7 +657,11 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // lane-quad kernel (4 lanes per env) for the rigid vehicles: fp32, 4 or 6 rotors, single-waypoint v2 task, default workgroup size
   const bool quad_ok = cfg->vehicle.n_joints == 0 && cfg->dtype == AMENV_F32 && (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) && !is_v1(cfg) &&
                        cfg->task.num_waypoints == 1 && cfg->block_size == 0;
-  e->quadk = quad_ok && (want == AMENV_KERNEL_AUTO ? cfg->num_envs <= kQuadAutoMax : want == AMENV_KERNEL_TEAM);
+  // Opt-in only (AMENV_KERNEL_TEAM), never AUTO: measured on MI355X (tools/gpu_quad.sh, profiles/r02/crossover_quad_vs_pw.txt) it ties with the
+  // helper-wave kernel where the launch is latency-bound (2.85 vs 2.86 us at 1024 envs, 2.98 vs 3.00 at 4096) and loses above (3.3 vs 3.2 us at
+  // 8192, 5.3 vs 4.3 at 32768: four times the wavefronts): at these sizes the rigid step sits on the dependent-launch floor (1.7 us) plus one
+  // load -> compute -> store round trip of memory latency, and an instruction stream half as long changes nothing.
+  e->quadk = quad_ok && want == AMENV_KERNEL_TEAM;
   if (e->quadk) e->pwave = false;
   if (want == AMENV_KERNEL_TEAM && !e->team && !e->quadk) {
     amenv_destroy(e);
@@ -1094,18 +1097,12 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 
-int amenv_ppo_adam_step(float* flat_params, float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6, float* grad_norm_out,
+int amenv_ppo_adam_step(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6, float* grad_norm_out,
                         uint32_t* ticket, void* stream) {
   if (!flat_params || !flat_grad || !exp_avg || !exp_avg_sq || !step || !hyper6 || !ticket || n <= 0) return AMENV_ERR_INVALID;
-  hipStream_t s = (hipStream_t)stream;
-  if (n <= kAdamSmall) {   // one workgroup: norm, barrier, update
-    hipLaunchKernelGGL(adam_clip_kernel, dim3(1), dim3(kAdamBlock), 0, s, flat_params, flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6, grad_norm_out);
-  } else {                 // a kernel boundary between the norm and the first overwritten gradient element
-    const int blocks = int(std::min<int64_t>(kAdamMaxBlocks, (n + kAdamBlock - 1) / kAdamBlock));
-    hipLaunchKernelGGL(adam_norm_kernel, dim3(1), dim3(kAdamBlock), 0, s, flat_grad, step, (int64_t)n, hyper6, grad_norm_out, reinterpret_cast<float*>(ticket));
-    hipLaunchKernelGGL(adam_apply_kernel, dim3(blocks), dim3(kAdamBlock), 0, s, flat_params, flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6,
-                       reinterpret_cast<const float*>(ticket));
-  }
+  const int blocks = int(std::min<int64_t>(kAdamMaxBlocks, (n + kAdamBlock - 1) / kAdamBlock));
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(kAdamBlock), 0, (hipStream_t)stream, flat_params, (const float*)flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6,
+                     grad_norm_out, ticket);
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 

@@ -450,81 +450,58 @@ __global__ __launch_bounds__(64 * kRedGroups) void mlp_grad_reduce_kernel(const 
   } else grad[tid] = tid < A ? t - ent_coef : t;
 }
 
-// Gradient-norm clip + Adam on the flat parameter buffer (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam, the step SB3's PPO.train()
-// takes).  The norm must be complete before ANY element of the gradient is overwritten with its clipped value -- a first version let
-// every workgroup of a multi-workgroup launch sum the whole buffer and then update its slice: a workgroup still summing could read
-// slices another one had already clipped (rare, timing-dependent: different clip factors in one step, run-to-run differences in the
-// last bits).  So the two phases are separated by a real barrier:
-//   * adam_clip_kernel:  ONE workgroup, norm -> __syncthreads -> update (n <= kAdamSmall: the reference policy has ~31 k parameters);
-//   * adam_norm_kernel + adam_apply_kernel: a kernel boundary between the phases for larger buffers; the norm travels in `word`.
-// `step` is torch's capturable-Adam step counter (a float on the device).
+// Gradient-norm clip + Adam on the flat parameter buffer in one launch (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam, the step SB3's
+// PPO.train() takes).  Every workgroup sums |scale * g|^2 over the WHOLE buffer in the same order (so all agree on the norm to the last
+// bit), then updates its slice.  The gradient buffer is READ-ONLY here: a first version wrote the clipped gradient back into it
+// (clip_grad_norm_'s in-place semantics), so a workgroup still summing could read slices another one had already clipped -- different
+// clip factors inside one step, run-to-run differences in the last bits (rare, timing-dependent; found by a bit-exact test failing once).
+// Nothing downstream reads the clipped gradient, so it is no longer stored; a one-workgroup variant with a barrier between the phases was
+// correct too but 20 us instead of 3.  `step` is torch's capturable-Adam step counter (a float on the device): read by every workgroup at
+// entry, incremented by the last one to finish (ticket), after every workgroup has read it.
 // hyper: [0] lr  [1] beta1  [2] beta2  [3] eps  [4] max_grad_norm (<= 0: no clipping)  [5] grad_scale (1 / world size after a sum all-reduce)
-constexpr int kAdamBlock = 1024, kAdamMaxBlocks = 256;
-constexpr int64_t kAdamSmall = 65536;
-
-// sum of (scale * g)^2 over the whole buffer by one workgroup in a fixed order; every thread returns the total
-__device__ __forceinline__ float adam_sumsq(const float* __restrict__ grad, int64_t n, float scale, float* sh) {
+constexpr int kAdamBlock = 1024, kAdamMaxBlocks = 64;
+__global__ __launch_bounds__(kAdamBlock) void adam_clip_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                                               float* __restrict__ step, int64_t n, const float* __restrict__ hyper, float* __restrict__ grad_norm,
+                                                               unsigned int* __restrict__ ticket) {
+  __shared__ float sh[kAdamBlock / 64];
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], max_norm = hyper[4], scale = hyper[5];
+  const float t = step[0] + 1.0f;
   float ss = 0.0f;
-  int64_t i = threadIdx.x;
-  for (; i + 7 * kAdamBlock < n; i += 8 * kAdamBlock) {     // eight loads in flight; the sum order is fixed by (thread, i)
-    float g[8];
+  {
+    int64_t i = threadIdx.x;
+    for (; i + 7 * kAdamBlock < n; i += 8 * kAdamBlock) {     // eight loads in flight; the sum order is fixed by (thread, i)
+      float g[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) g[j] = grad[i + j * kAdamBlock] * scale;
+      for (int j = 0; j < 8; j++) g[j] = grad[i + j * kAdamBlock] * scale;
 #pragma unroll
-    for (int j = 0; j < 8; j++) ss = fma_(g[j], g[j], ss);
+      for (int j = 0; j < 8; j++) ss = fma_(g[j], g[j], ss);
+    }
+    for (; i < n; i += kAdamBlock) { const float g = grad[i] * scale; ss = fma_(g, g, ss); }
   }
-  for (; i < n; i += kAdamBlock) { const float g = grad[i] * scale; ss = fma_(g, g, ss); }
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
   __syncthreads();
   float tot = 0.0f;
 #pragma unroll
   for (int k = 0; k < kAdamBlock / 64; k++) tot += sh[k];
-  return tot;
-}
-
-__device__ __forceinline__ void adam_update(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, int64_t i0,
-                                            int64_t i1, int64_t stride, const float* __restrict__ hyper, float gn, float t) {
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], max_norm = hyper[4], scale = hyper[5];
+  const float gn = sqrtf(tot);
   const float coef = max_norm > 0.0f ? fminf(max_norm / (gn + 1e-6f), 1.0f) * scale : scale;
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
-  for (int64_t i = i0; i < i1; i += stride) {
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x, i0 = int64_t(blockIdx.x) * per, i1 = i0 + per < n ? i0 + per : n;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += kAdamBlock) {
     const float g = grad[i] * coef;
     const float mi = fma_(g - m[i], 1.0f - b1, m[i]);                 // exp_avg.lerp_(grad, 1 - beta1)
     const float vi = fma_(g * g, 1.0f - b2, v[i] * b2);               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-    grad[i] = g; m[i] = mi; v[i] = vi;
+    m[i] = mi; v[i] = vi;
     param[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
   }
-}
-
-__global__ __launch_bounds__(kAdamBlock) void adam_clip_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
-                                                               float* __restrict__ step, int64_t n, const float* __restrict__ hyper, float* __restrict__ grad_norm) {
-  __shared__ float sh[kAdamBlock / 64];
-  const float t = step[0] + 1.0f;
-  const float gn = sqrtf(adam_sumsq(grad, n, hyper[5], sh));   // (its __syncthreads: every read of the norm pass has completed)
-  adam_update(param, grad, m, v, threadIdx.x, n, kAdamBlock, hyper, gn, t);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && grad_norm) grad_norm[0] = gn;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    if (grad_norm) grad_norm[0] = gn;
-    step[0] = t;
+    __threadfence();
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) { step[0] = t; *ticket = 0u; }
   }
-}
-
-__global__ __launch_bounds__(kAdamBlock) void adam_norm_kernel(const float* __restrict__ grad, float* __restrict__ step, int64_t n, const float* __restrict__ hyper,
-                                                               float* __restrict__ grad_norm, float* __restrict__ word) {
-  __shared__ float sh[kAdamBlock / 64];
-  const float gn = sqrtf(adam_sumsq(grad, n, hyper[5], sh));
-  if (threadIdx.x == 0) {
-    word[0] = gn;
-    if (grad_norm) grad_norm[0] = gn;
-    step[0] = step[0] + 1.0f;
-  }
-}
-
-__global__ __launch_bounds__(kAdamBlock) void adam_apply_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
-                                                                const float* __restrict__ step, int64_t n, const float* __restrict__ hyper,
-                                                                const float* __restrict__ word) {
-  adam_update(param, grad, m, v, int64_t(blockIdx.x) * kAdamBlock + threadIdx.x, n, int64_t(gridDim.x) * kAdamBlock, hyper, word[0], step[0]);
 }
 
 }  // namespace amenv_dev

@@ -10,6 +10,10 @@
 // the one-lane kernels (every branch is uniform within a quad, which keeps DPP legal inside it).  Episode ends: a helper wavefront per
 // workgroup evaluates the reset (Philox + reset_from_words) for all 16 rows while the main wave integrates, owns the workgroup's replica of
 // the Monitor totals and writes Monitor's outputs -- the step_kernel_team scheme.
+// MEASURED RESULT (MI355X, tools/gpu_quad.sh): no faster than step_kernel_pw -- 2.85 vs 2.86 us at 1024 envs, 2.98 vs 3.00 at 4096, slower from
+// 8192 envs on (four times the wavefronts).  The rigid step at these sizes is not bound by an instruction stream: it sits on the dependent-
+// launch floor (1.7 us) plus one load -> compute -> store round trip of memory latency.  Kept as an opt-in kernel (AMENV_KERNEL_TEAM on a
+// rigid vehicle; AUTO never selects it) because it is the evidence for that statement and shares its tests with the arm's team kernel.
 // Same expressions as amenv_model.hpp; sums over components associate differently (trees over lanes), so the result agrees with the
 // one-lane kernels to rounding (tests: teacher-forced golden episodes <= 1e-5, tracks the lane kernel <= 2e-6 per step), not bit for bit.
 #pragma once

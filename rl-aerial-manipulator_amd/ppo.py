@@ -302,7 +302,7 @@ class MinibatchStep:
         # clip + Adam in one launch on torch.optim.Adam's own state tensors (amenv_ppo_adam_step) where the optimiser is the plain Adam
         # on the flat buffer that `PPO` builds; anything else steps through torch
         self.fused_adam = self.fused_mlp and self._adam_is_plain(optimizer, policy)
-        self._adam_hyper = self._adam_key = self._adam_word = None
+        self._adam_hyper = self._adam_key = self._adam_ticket = None
         if self.fused_mlp and use_graph is None:
             self.use_graph = False                       # five launches per minibatch: nothing left for a graph to save
         self._static = None
@@ -399,12 +399,12 @@ class MinibatchStep:
         if key != self._adam_key:
             if self._adam_hyper is None:
                 self._adam_hyper = torch.empty(6, dtype=torch.float32, device=leaf.device)
-                self._adam_word = torch.zeros(1, dtype=torch.int32, device=leaf.device)
+                self._adam_ticket = torch.zeros(1, dtype=torch.int32, device=leaf.device)
             self._adam_hyper.copy_(torch.tensor(key, dtype=torch.float32))
             self._adam_key = key
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         rc = L.load().amenv_ppo_adam_step(p(pol.flat_param.detach()), p(pol.flat_grad), p(st["exp_avg"]), p(st["exp_avg_sq"]), p(st["step"]), pol.flat_param.numel(),
-                                          p(self._adam_hyper), C.c_void_p(self.stats.data_ptr() + 16), p(self._adam_word),
+                                          p(self._adam_hyper), C.c_void_p(self.stats.data_ptr() + 16), p(self._adam_ticket),
                                           C.c_void_p(torch.cuda.current_stream(leaf.device).cuda_stream))
         if rc != 0:
             raise L.AmenvError(f"amenv_ppo_adam_step failed ({rc})")

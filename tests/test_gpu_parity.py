@@ -679,8 +679,59 @@ def test_every_accepted_block_size_is_bit_identical(amd, vehicle, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vehicle,n", [("quad", 1), ("quad", 15), ("quad", 17), ("hexa", 65), ("hexa", 300), ("quad", 4096), ("hexa", 4096)])
+def test_quad_kernel_tracks_the_lane_kernel(amd, vehicle, n):
+    """The lane-quad kernel of the rigid vehicles (AMENV_KERNEL_TEAM, opt-in: 4 lanes per env, DPP exchanges) against the
+    one-lane-per-env kernel on the same inputs: same resets (bit-exact: same Philox words, same fp32 arithmetic), same flags, states
+    within fp32 rounding after every step (sums over components associate differently, so not bit for bit), Monitor totals equal;
+    ragged batches write nothing past row n."""
+    torch = _torch()
+    T = 150
+    g = torch.Generator(device="cuda").manual_seed(7)
+    acts = torch.randn(T, n, 4, device="cuda", generator=g) * 0.2
+    acts[..., 0] += 1.0
+    acts[:, ::3, 0] = 0.15                      # a third of the envs sink: crashes and auto-resets inside the window
+    acts = acts.clamp(-1, 2)
+    lane = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=6, kernel="lane", max_episode_steps=90)
+    quad = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=6, kernel="team", max_episode_steps=90)
+    assert "step_kernel_quad" in quad.kernel_name and "step_kernel<" in lane.kernel_name
+    o0 = lane.reset().clone(); o1 = quad.reset().clone()
+    assert torch.equal(o0, o1)
+    guard = torch.full((n + 8, 20), 7.0, device="cuda")       # the quad env writes its observations into rows [0, n) of this buffer only
+    worst = 0.0; flips = 0; dones = 0; bonus_flips = 0
+    for t in range(T):
+        f, i = lane.get_state()
+        quad.set_state(f, i)                                   # teacher-forced: both kernels step the same state
+        ol, rl, dl, il = (x.clone() for x in lane.step(acts[t]))
+        ot, rt, dt, it = quad.step_into(acts[t], guard[:n], quad.reward, quad.done)
+        same = (il & 127) == (it & 127)
+        flips += int((~same).sum())
+        f1, i1 = lane.get_state(); f2, i2 = quad.get_state()
+        nd = same & (dl == 0)
+        if bool(nd.any()):
+            worst = max(worst, float(((f1 - f2).abs() / f1.abs().clamp(min=1.0))[:15][:, nd].max()), float(((f1 - f2).abs() / f1.abs().clamp(min=1.0))[16:][:, nd].max()))
+            assert float((ol[nd] - ot[nd]).abs().max()) < 1e-5
+            dr = (rl - rt).abs()[nd]                           # rewards: rounding, or exactly the +2 progress bonus on its threshold
+            off = dr / rl.abs().clamp(min=1.0)[nd] >= 1e-4
+            bonus_flips += int(off.sum())
+            assert bool(((dr[off] - 2.0).abs() < 1e-3).all()), dr[off]
+        dn = same & (dl != 0)
+        dones += int(dn.sum())
+        assert torch.equal(f1[:, dn], f2[:, dn]) and torch.equal(i1[:, same], i2[:, same]) and torch.equal(ol[dn], ot[dn])   # reset states / observations: bit-exact
+        if bool(dn.any()):
+            assert torch.equal(lane.ep_len[dn], quad.ep_len[dn]) and float((lane.terminal_obs[dn] - quad.terminal_obs[dn]).abs().max()) < 1e-5
+            assert float((lane.ep_return[dn] - quad.ep_return[dn]).abs().max()) <= 2.0 + 1e-3 * float(lane.ep_return[dn].abs().max())
+    assert worst < 2e-6 and flips <= max(2, n // 500) and dones >= n // 4 and bonus_flips <= 1e-4 * n * T + 1, (worst, flips, dones, bonus_flips)
+    assert bool((guard[n:] == 7.0).all())
+    sl, sq = lane.stats(), quad.stats()
+    assert abs(sl["episodes"] - sq["episodes"]) <= flips and sl["steps"] == sq["steps"]
+    lane.close(); quad.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("vehicle,kernel,n", [("hexa", "auto", 4096), ("quad", "auto", 1000), ("hexa", "lane", 1000), ("hexa_arm", "team", 4096),
-                                              ("hexa_arm", "team", 7000), ("hexa_arm", "helper", 1000), ("hexa_arm", "lane", 640), ("hexa_arm", "staged", 1000)])
+                                              ("hexa_arm", "team", 7000), ("hexa_arm", "helper", 1000), ("hexa_arm", "lane", 640), ("hexa_arm", "staged", 1000),
+                                              ("hexa", "helper", 4096), ("quad", "team", 1000), ("hexa", "team", 20000)])
 def test_monitor_totals_and_episode_outputs_match_the_per_step_outputs(amd, vehicle, kernel, n):
     """The running totals (`amenv_stats_read`) and the per-episode outputs (ep_return, ep_len, terminal_obs) are written by helper
     wavefronts in the small-batch kernels (owned replicas, no atomics); whatever writes them, they must equal what the per-step outputs
