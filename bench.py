@@ -312,7 +312,8 @@ def main_worker(args):
         kernel_us = dev_ms / K * 1e3
         kn = env.kernel_name
         tiles = (n + 63) // 64
-        waves = (n + 3) // 4 * 2 if "team" in kn else tiles * (2 if "arm2w" in kn else ((4 if "KW=1,v2" in kn else 2) if "step_kernel_pw" in kn else 1))
+        waves = ((n + 3) // 4 * 2 if "team" in kn else (n + 15) // 16 * 2 if "step_kernel_quad" in kn else
+                 tiles * (5 if "armk" in kn else 2 if "arm2w" in kn else ((4 if "KW=1,v2" in kn else 2) if "step_kernel_pw" in kn else 1)))
         out["roofline"] = {
             "bound": "hbm", "achieved": n * bytes_step / (kernel_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": n * bytes_step / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
