@@ -369,7 +369,7 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
  * PPO.train(); Adam with eps 1e-5, v2/rl_train.py:38 through SB3's defaults).  exp_avg / exp_avg_sq / step: torch.optim.Adam's state for
  * that parameter (step: ONE f32 on the device, as torch keeps it with capturable=True; incremented here).  hyper6 (device): lr, beta1,
  * beta2, eps, max_grad_norm (<= 0: no clipping), grad_scale (multiplies the gradient first: 1 / world size after a sum all-reduce).
- * flat_grad is READ-ONLY (the clipped gradient is applied, not stored: every workgroup of the launch takes the norm of the whole buffer
+ * flat_grad (16-byte aligned) is READ-ONLY (the clipped gradient is applied, not stored: every workgroup of the launch takes the norm of the whole buffer
  * as it was on entry), grad_norm_out (may be NULL) receives the norm before clipping.  ticket: one zero-initialised device word the
  * kernel uses and leaves zero. */
 int amenv_ppo_adam_step(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6,

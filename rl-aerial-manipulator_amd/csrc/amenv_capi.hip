@@ -1082,8 +1082,8 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
   const int adv_blocks = int(std::min<int64_t>(kPpoMaxBlocks, (n + kPpoBlock - 1) / kPpoBlock));
   const int64_t ntiles = (n + 31) / 32;
   const int blocks = int(std::min<int64_t>(128, (ntiles + 3) / 4));   // 128 x 2 nets x 4 wavefronts = one wavefront per SIMD
-  hipLaunchKernelGGL(ppo_adv_partials, dim3(adv_blocks), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part, index);
-  hipLaunchKernelGGL(mlp_transpose_kernel, dim3((2 * kMlpWtPerNet + 255) / 256), dim3(256), 0, s, flat_params, (int)obs_dim, (int)act_dim, WT);
+  hipLaunchKernelGGL(ppo_mlp_prologue_kernel, dim3(adv_blocks + (2 * kMlpWtPerNet + kPpoBlock - 1) / kPpoBlock), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part, index,
+                     adv_blocks, flat_params, (int)obs_dim, (int)act_dim, WT);
   hipError_t st;
   if (obs_dim == 20 && act_dim == 4) st = launch_mlp_step<20, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
   else if (obs_dim == 29 && act_dim == 7) st = launch_mlp_step<29, 7>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
@@ -1099,7 +1099,7 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
 
 int amenv_ppo_adam_step(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6, float* grad_norm_out,
                         uint32_t* ticket, void* stream) {
-  if (!flat_params || !flat_grad || !exp_avg || !exp_avg_sq || !step || !hyper6 || !ticket || n <= 0) return AMENV_ERR_INVALID;
+  if (!flat_params || !flat_grad || !exp_avg || !exp_avg_sq || !step || !hyper6 || !ticket || n <= 0 || !aligned16(flat_grad)) return AMENV_ERR_INVALID;
   const int blocks = int(std::min<int64_t>(kAdamMaxBlocks, (n + kAdamBlock - 1) / kAdamBlock));
   hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(kAdamBlock), 0, (hipStream_t)stream, flat_params, (const float*)flat_grad, exp_avg, exp_avg_sq, step, (int64_t)n, hyper6,
                      grad_norm_out, ticket);

@@ -65,8 +65,7 @@ __device__ __forceinline__ MlpNet mlp_net(const float* Pm, int D, int A, int net
 }
 
 // k-major copies of the four weight matrices of both nets (forward-pass A operands): one thread per element
-__global__ void mlp_transpose_kernel(const float* __restrict__ Pm, int D, int A, float* __restrict__ WT) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void mlp_transpose_element(const float* __restrict__ Pm, int D, int A, float* __restrict__ WT, int tid) {
   if (tid >= 2 * kMlpWtPerNet) return;
   const int net = tid / kMlpWtPerNet, e = tid % kMlpWtPerNet;
   const MlpNet N = mlp_net(Pm, D, A, net);
@@ -77,6 +76,17 @@ __global__ void mlp_transpose_kernel(const float* __restrict__ Pm, int D, int A,
   else if (e < 32 * kH1 + kH1 * kH2 + kH2 * kH3 + kH3 * 32) { const int q = e - 32 * kH1 - kH1 * kH2 - kH2 * kH3, k = q / 32, n = q % 32; v = n < N.n_out ? N.W4[n * kH3 + k] : 0.0f; }
   else { const int q = e - 32 * kH1 - kH1 * kH2 - kH2 * kH3 - kH3 * 32, o = q / kH3, k = q % kH3; v = o < N.n_out ? N.W4[o * kH3 + k] : 0.0f; }
   WT[tid] = v;
+}
+__global__ void mlp_transpose_kernel(const float* __restrict__ Pm, int D, int A, float* __restrict__ WT) {
+  mlp_transpose_element(Pm, D, A, WT, int(blockIdx.x * blockDim.x + threadIdx.x));
+}
+// Everything the fused kernel needs beforehand in ONE launch (each launch in this chain costs ~4.7 us whatever it does): workgroups
+// [0, adv_blocks) sum the minibatch's advantages (ppo_adv_partials), the rest write the k-major weight copies.  256 threads.
+__global__ __launch_bounds__(kPpoBlock) void ppo_mlp_prologue_kernel(const float* __restrict__ adv, int64_t n, double* __restrict__ adv_part,
+                                                                     const int64_t* __restrict__ index, int adv_blocks, const float* __restrict__ Pm, int D, int A,
+                                                                     float* __restrict__ WT) {
+  if (int(blockIdx.x) < adv_blocks) ppo_adv_partials_block(adv, n, adv_part, index, int(blockIdx.x), adv_blocks);   // uniform per workgroup
+  else mlp_transpose_element(Pm, D, A, WT, (int(blockIdx.x) - adv_blocks) * kPpoBlock + int(threadIdx.x));
 }
 
 // out[tile] = sum_k Wk[k][32 tile + n] * in[k]  (+ bias), k = 32 t + rowmap(r) + 4 h over the KT input tiles.  Wk is k-major ([K][ld]),
@@ -467,16 +477,26 @@ __global__ __launch_bounds__(kAdamBlock) void adam_clip_kernel(float* __restrict
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], max_norm = hyper[4], scale = hyper[5];
   const float t = step[0] + 1.0f;
   float ss = 0.0f;
-  {
+  {   // 16-byte loads, eight in flight per thread (the buffer is 16-byte aligned: checked by the caller); the sum order is fixed by (thread, i)
+    const int64_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(grad);
     int64_t i = threadIdx.x;
-    for (; i + 7 * kAdamBlock < n; i += 8 * kAdamBlock) {     // eight loads in flight; the sum order is fixed by (thread, i)
-      float g[8];
+    for (; i + 7 * kAdamBlock < n4; i += 8 * kAdamBlock) {
+      float4 g[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) g[j] = grad[i + j * kAdamBlock] * scale;
+      for (int j = 0; j < 8; j++) g[j] = g4[i + j * kAdamBlock];
 #pragma unroll
-      for (int j = 0; j < 8; j++) ss = fma_(g[j], g[j], ss);
+      for (int j = 0; j < 8; j++) {
+        const float a = g[j].x * scale, b = g[j].y * scale, c = g[j].z * scale, d = g[j].w * scale;
+        ss = fma_(a, a, ss); ss = fma_(b, b, ss); ss = fma_(c, c, ss); ss = fma_(d, d, ss);
+      }
     }
-    for (; i < n; i += kAdamBlock) { const float g = grad[i] * scale; ss = fma_(g, g, ss); }
+    for (; i < n4; i += kAdamBlock) {
+      const float4 q = g4[i];
+      const float a = q.x * scale, b = q.y * scale, c = q.z * scale, d = q.w * scale;
+      ss = fma_(a, a, ss); ss = fma_(b, b, ss); ss = fma_(c, c, ss); ss = fma_(d, d, ss);
+    }
+    for (int64_t k = (n4 << 2) + threadIdx.x; k < n; k += kAdamBlock) { const float g = grad[k] * scale; ss = fma_(g, g, ss); }
   }
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;

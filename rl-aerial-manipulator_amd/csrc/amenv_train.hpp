@@ -103,11 +103,12 @@ constexpr int kPpoBlock = 256;
 constexpr int kPpoMaxBlocks = 1024;
 constexpr int kPpoPartial = AMENV_MAX_JOINTS + kActDim + 4;   // d log_std[<=7] + policy / value / clip-fraction sums (+1 spare)
 
-__global__ __launch_bounds__(kPpoBlock) void ppo_adv_partials(const float* __restrict__ adv, int64_t n, double* __restrict__ part,
-                                                              const int64_t* __restrict__ index = nullptr) {
+// body of ppo_adv_partials for block `blk` of `nblk` (also called from the fused minibatch step's prologue kernel, amenv_mlp_train.hpp)
+__device__ __forceinline__ void ppo_adv_partials_block(const float* __restrict__ adv, int64_t n, double* __restrict__ part, const int64_t* __restrict__ index,
+                                                       int blk, int nblk) {
   __shared__ double sh[2][kPpoBlock / 64];
   double s = 0.0, q = 0.0;
-  for (int64_t i = int64_t(blockIdx.x) * kPpoBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kPpoBlock) {
+  for (int64_t i = int64_t(blk) * kPpoBlock + threadIdx.x; i < n; i += int64_t(nblk) * kPpoBlock) {
     const double a = adv[index ? index[i] : i];
     s += a; q += a * a;
   }
@@ -118,8 +119,12 @@ __global__ __launch_bounds__(kPpoBlock) void ppo_adv_partials(const float* __res
   if (threadIdx.x == 0) {
     double S = 0.0, Q = 0.0;
     for (int k = 0; k < kPpoBlock / 64; k++) { S += sh[0][k]; Q += sh[1][k]; }
-    part[2 * blockIdx.x] = S; part[2 * blockIdx.x + 1] = Q;
+    part[2 * blk] = S; part[2 * blk + 1] = Q;
   }
+}
+__global__ __launch_bounds__(kPpoBlock) void ppo_adv_partials(const float* __restrict__ adv, int64_t n, double* __restrict__ part,
+                                                              const int64_t* __restrict__ index = nullptr) {
+  ppo_adv_partials_block(adv, n, part, index, int(blockIdx.x), int(gridDim.x));
 }
 
 template <int A>
