@@ -375,6 +375,14 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
 int amenv_ppo_adam_step(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* step, int64_t n, const float* hyper6,
                         float* grad_norm_out, uint32_t* ticket, void* stream);
 
+/* Parity gate of the arm vehicle's arithmetic (no reference dynamics exist for it; DESIGN.md "arm"): the 19 state derivatives of n states
+ * [n, 19] = (p, v, q, w, th, thd) under post-mixer wrenches [n, 4] = (F, Mx, My, Mz) and joint commands [n, 3], deriv [n, 19], all of `dtype`
+ * (AMENV_F32 | AMENV_F64), on the current device.  form 0: the per-link Newton-Euler sums the lane and two-wave kernels run; form 1: the staged
+ * form (joint-configuration aggregates, then the base dynamics on them) the stage-wave and lane-team kernels run.  Tests compare both fp64
+ * instantiations with the oracle's right-hand side (<= 1e-12).  cfg: an arm vehicle with the z,x,x joint axes. */
+int amenv_arm_rhs(const amenv_config* cfg, int32_t form, int32_t dtype, const void* state19, const void* wrench4, const void* cmd3, void* deriv19,
+                  int64_t n, void* stream);
+
 /* ---- PID + minimum-snap baseline controller ------------------------------------------------------------
  * The reference's hand-tuned controller, `v2/PID Controller/{pid_controller,trajGen3D,runsim}.py`, for N vehicles per launch on caller-owned
  * device buffers of the CURRENT device.  `dtype` selects the arithmetic of the float buffers marked (dtype): AMENV_F64 = the logic gate

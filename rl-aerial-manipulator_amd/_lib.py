@@ -107,6 +107,7 @@ SYMBOLS = {
     "amenv_ppo_mlp_workspace_bytes": (C.c_size_t, []),
     "amenv_ppo_mlp_step": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 6 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, _P, _P, _P, _P]),
     "amenv_ppo_adam_step": (C.c_int, [_P] * 5 + [C.c_int64, _P, _P, _P, _P]),
+    "amenv_arm_rhs": (C.c_int, [C.POINTER(Config), C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int64, _P]),
     "amenv_pid_default_params": (C.c_int, [C.POINTER(PidParams)]),
     "amenv_pid_run": (C.c_int, [C.POINTER(PidParams), C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "amenv_minsnap_workspace_bytes": (C.c_size_t, [C.c_int32]),

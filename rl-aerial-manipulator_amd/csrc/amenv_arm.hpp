@@ -782,4 +782,34 @@ __device__ __forceinline__ void dynamics_arm_staged(const HotParams<T, NROT>& P,
   for (int j = 0; j < 3; j++) { e.th[j] = T(x.jn[j * 64 + x.lane]); e.thd[j] = T(x.jn[(3 + j) * 64 + x.lane]); }
 }
 
+// Parity gate of the two formulations of the right-hand side (amenv_arm_rhs): the 19 derivatives of n states [n][19] under wrench [n][4]
+// (F, Mx, My, Mz after the mixer) and joint commands [n][3], per-link form (arm_rhs_body) or staged form (arm_kin_aggregates + arm_dyn_agg),
+// in the arithmetic type T -- the fp64 instantiation is compared with the fp64 oracle's orc_arm_rhs.  z,x,x arm.
+template <typename T, int FORM, typename PT>
+__global__ void arm_rhs_kernel(const PT P, const ArmParams<T> A, const T* __restrict__ s, const T* __restrict__ wrench, const T* __restrict__ cmd,
+                               T* __restrict__ d, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T y[19], c[3], out[19];
+#pragma unroll
+  for (int k = 0; k < 19; k++) y[k] = s[i * 19 + k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) c[k] = cmd[i * 3 + k];
+  const T F = wrench[i * 4];
+  const V3<T> M{wrench[i * 4 + 1], wrench[i * 4 + 2], wrench[i * 4 + 3]};
+  if constexpr (FORM == 0) {
+    arm_rhs<AxesZXX>(P, A, y, F, M, c, out);
+  } else {
+    T thdd[3], g[kAggSlots];
+#pragma unroll
+    for (int k = 0; k < 3; k++) thdd[k] = servo_(A, c[k], y[13 + k], y[16 + k]);
+    arm_kin_aggregates<T>(P, A, &y[13], &y[16], thdd, g);
+    arm_dyn_agg<T>(P, A, y, F, M, g, out);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { out[13 + k] = y[16 + k]; out[16 + k] = thdd[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 19; k++) d[i * 19 + k] = out[k];
+}
+
 }  // namespace amenv_dev

@@ -1106,6 +1106,32 @@ int amenv_ppo_adam_step(float* flat_params, const float* flat_grad, float* exp_a
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 
+// Right-hand side of the arm vehicle for n states, per-link (form 0) or staged / aggregated (form 1) formulation, fp32 or fp64: the logic gate of
+// the arithmetic the stage-wave and lane-team kernels run (tests compare the fp64 instantiation with the oracle's orc_arm_rhs).
+int amenv_arm_rhs(const amenv_config* cfg, int32_t form, int32_t dtype, const void* state19, const void* wrench4, const void* cmd3, void* deriv19, int64_t n,
+                  void* stream) {
+  if (validate(cfg) || cfg->vehicle.n_joints != 3 || cfg->vehicle.n_rotors != 6 || (form != 0 && form != 1) || (dtype != AMENV_F32 && dtype != AMENV_F64) ||
+      !state19 || !wrench4 || !cmd3 || !deriv19 || n <= 0)
+    return AMENV_ERR_INVALID;
+  amenv tmp;
+  tmp.cfg = *cfg;
+  if (make_arm<float>(tmp).generic_axes) return AMENV_ERR_INVALID;   // z,x,x arm
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == AMENV_F64) {
+    const HotParams<double, 6> P = make_hot<double, 6>(tmp);
+    const ArmParams<double> A = make_arm<double>(tmp);
+    if (form == 0) hipLaunchKernelGGL((arm_rhs_kernel<double, 0, HotParams<double, 6>>), grid, block, 0, s, P, A, (const double*)state19, (const double*)wrench4, (const double*)cmd3, (double*)deriv19, (int64_t)n);
+    else hipLaunchKernelGGL((arm_rhs_kernel<double, 1, HotParams<double, 6>>), grid, block, 0, s, P, A, (const double*)state19, (const double*)wrench4, (const double*)cmd3, (double*)deriv19, (int64_t)n);
+  } else {
+    const HotParams<float, 6> P = make_hot<float, 6>(tmp);
+    const ArmParams<float> A = make_arm<float>(tmp);
+    if (form == 0) hipLaunchKernelGGL((arm_rhs_kernel<float, 0, HotParams<float, 6>>), grid, block, 0, s, P, A, (const float*)state19, (const float*)wrench4, (const float*)cmd3, (float*)deriv19, (int64_t)n);
+    else hipLaunchKernelGGL((arm_rhs_kernel<float, 1, HotParams<float, 6>>), grid, block, 0, s, P, A, (const float*)state19, (const float*)wrench4, (const float*)cmd3, (float*)deriv19, (int64_t)n);
+  }
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
 // ---- PID + minimum-snap baseline controller (row f4; csrc/amenv_baseline.hpp) ---------------------------------------------------------
 int amenv_pid_default_params(amenv_pid_params* p) {
   if (!p) return AMENV_ERR_INVALID;

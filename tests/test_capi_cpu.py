@@ -51,6 +51,8 @@ def test_pid_default_params_are_the_reference_gains():
     assert L.amenv_minsnap_solve(0, 1, 1.2, None, None, None, None, None, None) == -1
     assert L.amenv_minsnap_eval(4, 0, None, None, None, None, None, None, 1, None, None) == -1
     assert L.amenv_pid_policy(None, 0, None, None, None, None, 1, None) == -1
+    arm = amd._lib.default_config("hexa_arm", 1)
+    assert L.amenv_arm_rhs(C.byref(arm), 2, 1, None, None, None, None, 4, None) == -1 and L.amenv_arm_rhs(C.byref(arm), 1, 1, None, None, None, None, 4, None) == -1
 
 
 def test_default_quad_equals_oracle_constants():

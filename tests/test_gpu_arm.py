@@ -457,3 +457,34 @@ def test_closed_loop_policy_rollout_forms_draw_the_same_actions():
     assert int(same.sum()) > n // 2
     assert torch.equal(a1[0][same], a2[0][same]) and torch.equal(l1[0][same], l2[0][same]) and torch.equal(v1[0][same], v2[0][same])
     assert float((o1[1] - o2[1]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("form", [0, 1])
+def test_arm_right_hand_side_device_code_vs_oracle(form):
+    """amenv_arm_rhs: the device code of both formulations of the arm vehicle's right-hand side -- form 0 = per-link Newton-Euler sums
+    (lane / two-wave kernels), form 1 = joint-configuration aggregates + base dynamics on them (stage-wave / lane-team kernels) -- on
+    random states, wrenches and commands: the fp64 instantiation against the fp64 oracle (logic gate, <= 1e-12), the fp32 instantiation
+    to fp32 rounding.  A third of the commands saturate the joint servos."""
+    import ctypes as C
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n = 4096
+    rng = np.random.RandomState(21 + form)
+    s = np.zeros((n, 19))
+    s[:, :6] = rng.normal(size=(n, 6)); q = rng.normal(size=(n, 4)); s[:, 6:10] = q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.98, 1.02, (n, 1))
+    s[:, 10:13] = rng.normal(size=(n, 3)) * 2; s[:, 13:16] = rng.uniform(-1.5, 1.5, (n, 3)); s[:, 16:19] = rng.normal(size=(n, 3)) * 2
+    w = np.concatenate([rng.uniform(5, 60, (n, 1)), rng.normal(size=(n, 3))], 1)
+    cmd = s[:, 13:16] + rng.normal(size=(n, 3)) * np.where(rng.rand(n, 1) < 0.33, 2.0, 0.05)
+    cfg = amd._lib.default_config("hexa_arm", 1)
+    ocfg = arm_cfg()
+    ref = np.stack([O.arm_rhs(ocfg, s[i], w[i, 0], w[i, 1:], cmd[i]) for i in range(n)])
+    scale = np.maximum(1.0, np.abs(ref))
+    for dtype, code, tol in ((torch.float64, amd._lib.F64, 1e-12), (torch.float32, amd._lib.F32, 3e-5)):
+        ts, tw, tc = (torch.as_tensor(a, dtype=dtype).cuda().contiguous() for a in (s, w, cmd))
+        d = torch.empty(n, 19, dtype=dtype, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        assert amd._lib.load().amenv_arm_rhs(C.byref(cfg), form, code, p(ts), p(tw), p(tc), p(d), n, None) == 0
+        err = (np.abs(d.cpu().numpy().astype(np.float64) - ref) / scale).max()
+        assert err < tol, (form, dtype, err)
+    # a rigid vehicle has no such right-hand side
+    assert amd._lib.load().amenv_arm_rhs(C.byref(amd._lib.default_config("hexa", 1)), form, amd._lib.F64, p(ts), p(tw), p(tc), p(d), n, None) == -1
