@@ -258,8 +258,9 @@ def main_worker(args):
         run_timed()
         if not dry:
             ev1.record()
-        sync(); barrier()
-        wall = time.perf_counter() - t0
+        sync()
+        wall = time.perf_counter() - t0   # this rank's K steps, launch to completion; the job's time is the MAX over ranks (below)
+        barrier()                         # closes the bracket; its own latency (an RCCL all-reduce) is not part of any rank's K steps
         dev_ms = ev0.elapsed_time(ev1) if not dry else wall * 1e3
         windows.append((amd.sharding.max_over_ranks(dist, wall, device), dev_ms))
     stats = env.stats()
