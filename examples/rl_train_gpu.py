@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--resume", default=None, help="SB3 zip / policy.pth to start from (rl_train.py:33-35)")
     ap.add_argument("--save", default="waypoint_controller_gpu")         # rl_train.py:57
     ap.add_argument("--vehicle", default="quad")
+    ap.add_argument("--moment-scale", type=float, default=None, help="N m per unit moment action (amenv_vehicle.moment_scale; the reference quadrotor: 0.1)")
     a = ap.parse_args()
     import torch
     import rl_aerial_manipulator_amd as amd
@@ -34,7 +35,12 @@ def main():
     torch.cuda.set_device(local)
     sh = sharding.shard_from_env(a.envs)
     dist = sharding.init_process_group("nccl", torch.device("cuda", local))
-    env = amd.GpuWaypointEnv(a.envs, device=local, vehicle=a.vehicle, seed=0, env_id_offset=sh.env_id_offset)
+    cfg = None
+    if a.moment_scale is not None:
+        cfg = amd._lib.default_config(a.vehicle, a.envs)
+        cfg.vehicle.moment_scale = a.moment_scale
+        cfg.seed, cfg.env_id_offset = 0, sh.env_id_offset
+    env = amd.GpuWaypointEnv(a.envs, device=local, vehicle=a.vehicle, seed=0, env_id_offset=sh.env_id_offset, config=cfg)
     model = amd.PPO(env, learning_rate=2e-4, n_steps=a.n_steps, batch_size=a.envs * a.n_steps // 128, n_epochs=12, gamma=0.995,
                     gae_lambda=0.9, clip_range=0.2, ent_coef=1e-4 if a.resume else 5e-4, dist=dist)
     if a.resume:

@@ -488,3 +488,45 @@ def test_arm_right_hand_side_device_code_vs_oracle(form):
         assert err < tol, (form, dtype, err)
     # a rigid vehicle has no such right-hand side
     assert amd._lib.load().amenv_arm_rhs(C.byref(amd._lib.default_config("hexa", 1)), form, amd._lib.F64, p(ts), p(tw), p(tc), p(d), n, None) == -1
+
+
+@pytest.mark.parametrize("kernel,n", [("lane", 300), ("helper", 300), ("team", 300), ("auto", 8192)])
+@pytest.mark.parametrize("substeps", [2, 3])
+def test_arm_rk4_substeps_vs_oracle(substeps, kernel, n):
+    """amenv_task.rk4_substeps > 1 (several RK4 steps of dt / substeps per control step) on every arm kernel that carries it, teacher-forced
+    against the oracle with the same setting; the stage-wave kernel is built for one sub-step: refused when asked for, not selected by AUTO."""
+    import rl_aerial_manipulator_amd as amd
+    rng = np.random.RandomState(5)
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, kernel=kernel, rk4_substeps=substeps, max_episode_steps=50)
+    assert "armk" not in env.kernel_name and (kernel != "auto" or "arm2w" in env.kernel_name)
+    with pytest.raises(amd.AmenvError, match="AMENV_KERNEL_STAGED"):
+        amd.GpuWaypointEnv(64, vehicle="hexa_arm", kernel="staged", rk4_substeps=substeps)
+    orc = orc_arm(n, seed=3)
+    orc.cfg.task.rk4_substeps = substeps; orc.cfg.task.max_episode_steps = 50
+    env.reset()
+    f, i = gpu_state(env)
+    q = rng.normal(size=(4, n)) * 0.2; q[0] += 1; q /= np.linalg.norm(q, axis=0)
+    f[6:10] = q; f[10:13] = rng.normal(0, 1.0, (3, n)); f[19:22] = rng.uniform(-1, 1, (3, n)); f[22:25] = rng.normal(0, 1.0, (3, n))
+    env.set_state(f.astype(np.float32), i)
+    worst = 0.0; flips = 0
+    for t in range(40):
+        g, o = both_step(env, orc, rand_actions(rng, n))
+        f2, i2 = gpu_state(env)
+        bad = (g["info"] & 127) != (o["info"] & 127)
+        flips += int(bad.sum())
+        nd = ~bad & (o["done"] == 0)
+        rows = np.r_[0:15, 16:25]
+        worst = max(worst, rel_err(f2[rows][:, nd], orc.fstate[rows][:, nd]).max())
+    assert worst < 3e-6 and flips <= 2, (worst, flips)
+    # the setting changes the trajectory (a 5 ms RK4 step vs two of 2.5 ms differ at the 1e-9 level per step: visible in fp64 only) -- check it
+    # is honoured through a quantity it changes at first order: with substeps the step still advances dt, not dt / substeps
+    one = amd.GpuWaypointEnv(64, vehicle="hexa_arm", seed=3, kernel="lane", dtype="f64")
+    sub = amd.GpuWaypointEnv(64, vehicle="hexa_arm", seed=3, kernel="lane", dtype="f64", rk4_substeps=substeps)
+    a = np.tile(np.array([[1.3, 0, 0, 0, 0.5, 0.5, 0.5]], np.float32), (64, 1))
+    import torch
+    one.reset(); sub.reset()
+    for _ in range(20):
+        one.step(torch.from_numpy(a).cuda()); sub.step(torch.from_numpy(a).cuda())
+    f1, _ = gpu_state(one); f2_, _ = gpu_state(sub)
+    d = np.abs(f1[:13] - f2_[:13]).max()
+    assert 0 < d < 1e-6, d          # same motion to integration error, not bit for bit

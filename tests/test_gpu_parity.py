@@ -679,6 +679,38 @@ def test_every_accepted_block_size_is_bit_identical(amd, vehicle, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vehicle,kernel", [("quad", "lane"), ("quad", "helper"), ("hexa", "auto"), ("hexa", "team")])
+@pytest.mark.parametrize("substeps", [2, 4])
+def test_rk4_substeps_vs_oracle(amd, vehicle, kernel, substeps):
+    """amenv_task.rk4_substeps > 1 on the rigid kernels (one-lane, helper-wave, lane-quad), teacher-forced against the oracle with the same
+    setting: state within the fp32 gate, flags equal."""
+    import ctypes as C
+    n = 1000
+    rng = np.random.RandomState(8)
+    env = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=2, kernel=kernel, rk4_substeps=substeps, max_episode_steps=60)
+    cfg = O.reference_quad_config(num_envs=n, seed=2)
+    C.memmove(C.byref(cfg.vehicle), C.byref(env.cfg.vehicle), C.sizeof(O.Vehicle))
+    cfg.task.rk4_substeps = substeps; cfg.task.max_episode_steps = 60
+    orc = O.OracleEnv(cfg)
+    env.reset(); orc.reset()
+    worst = 0.0; flips = 0
+    torch = _torch()
+    for t in range(60):
+        f, i = gpu_state(env)
+        orc.fstate[:] = f; orc.istate[:] = i
+        a = rng.uniform([0.5, -1, -1, -1], [1.5, 1, 1, 1], (n, 4)).astype(np.float32); a[:, 1:] *= 0.2; a[::6, 0] = 0.0
+        obs, rew, done, info = env.step(torch.from_numpy(a).cuda())
+        o = orc.step(a)
+        f2, i2 = gpu_state(env)
+        bad = (info.cpu().numpy().view(np.uint32) & 127) != (o["info"] & 127)
+        flips += int(bad.sum())
+        nd = ~bad & (o["done"] == 0)
+        worst = max(worst, rel_err(f2[:15][:, nd], orc.fstate[:15][:, nd]).max())
+    assert worst < 1e-5 and flips <= 2, (worst, flips)
+    env.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("vehicle,n", [("quad", 1), ("quad", 15), ("quad", 17), ("hexa", 65), ("hexa", 300), ("quad", 4096), ("hexa", 4096)])
 def test_quad_kernel_tracks_the_lane_kernel(amd, vehicle, n):
     """The lane-quad kernel of the rigid vehicles (AMENV_KERNEL_TEAM, opt-in: 4 lanes per env, DPP exchanges) against the
