@@ -327,8 +327,9 @@ int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_
  *   by (seed, global env id, draw0 + t) as amenv_gaussian_act) -> clip to the action box -> env step (as amenv_step, auto-reset included).
  * State, per-lane constants and the policy weights stay in registers between steps.  Built for the fp32 6-rotor vehicle with the z,x,x
  * arm (obs_dim 29, act_dim 7); other configurations return AMENV_ERR_INVALID.  The env part is the arithmetic of the kernel amenv_step
- * runs for this env (16 lanes per env where that is the lane-team kernel, else one lane per env: replaying the recorded clipped actions
- * through amenv_step reproduces every row bit for bit); both forms draw the same noise.  An opt-in ROLLOUT mode: bf16
+ * runs for this env (16 lanes per env where that is the lane-team kernel, else one lane per env with the arithmetic of the LANE / HELPER step
+ * kernels: replaying the recorded clipped actions through amenv_step on such a handle reproduces every row bit for bit; a handle whose
+ * amenv_step runs the STAGED kernel agrees to rounding); both forms draw the same noise.  An opt-in ROLLOUT mode: bf16
  * rounding perturbs the action means by ~1e-2 of their scale; log-probs are those of the samples under the means actually used.
  *   flat_params  fp32 policy parameters in SB3 state-dict order (see amenv_policy_forward)
  *   obs          [n_steps + 1, N, 29] f32: row 0 <- observation at entry, row t + 1 <- after step t (post-reset for done envs)
