@@ -195,3 +195,19 @@ def test_pid_policy_is_one_launch_on_device():
     import ctypes as C
     p = amd._lib.PidPolicyParams(pid=pol.pid.params(), speed=0.6, moment_scale=0.1, obs_dim=19, act_dim=4)
     assert amd._lib.load().amenv_pid_policy(C.byref(p), 0, C.c_void_p(a.data_ptr()), None, C.c_void_p(pol.pstate.data_ptr()), C.c_void_p(a.data_ptr()), 256, None) == -1
+
+
+def test_runsim_example_runs():
+    """examples/runsim_gpu.py (the reference's PID demo loop for N vehicles on the GPU) end to end: every vehicle flies its own helix within
+    tracking distance of its trajectory and the ones that finish hover on their last waypoint."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "runsim_gpu.py"), "--vehicles", "256", "--steps", "1500"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"worst tracking error per vehicle: median ([0-9.]+) m, max ([0-9.]+) m", r.stdout)
+    assert m and float(m.group(1)) < 0.5 and float(m.group(2)) < 1.5, r.stdout
+    m2 = re.search(r"(\d+) vehicles finished their trajectory: distance to the last waypoint median ([0-9.]+) m", r.stdout)
+    assert m2 and int(m2.group(1)) > 10 and float(m2.group(2)) < 0.05, r.stdout
