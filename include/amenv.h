@@ -56,7 +56,7 @@ extern "C" {
 #define AMENV_KERNEL_AUTO 0
 #define AMENV_KERNEL_LANE 1   /* one lane per env, one wavefront per 64-env tile                                      */
 #define AMENV_KERNEL_HELPER 2 /* LANE + helper wavefronts per tile (reset RNG words, observation rows, arm link 3)     */
-#define AMENV_KERNEL_TEAM 3   /* arm vehicle: a team of 16 lanes (one DPP row) per env, AUTO up to 6144 envs; rigid vehicles: 4 lanes (one
+#define AMENV_KERNEL_TEAM 3   /* arm vehicle: a team of 16 lanes (one DPP row) per env, AUTO up to 8192 envs; rigid vehicles: 4 lanes (one
                                  DPP quad) per env, opt-in only (measured no faster than HELPER)                          */
 #define AMENV_KERNEL_STAGED 4 /* arm vehicle: the four RK4 stages' joint-configuration work on four wavefronts side by side,
                                  the base dynamics on their 36-number aggregates on a fifth (not bit-identical to LANE)  */

@@ -52,6 +52,7 @@ struct amenv {
 };
 
 static thread_local std::string g_create_err;
+constexpr int kTeamAutoMax = 8192;    // AUTO: lane-team arm kernel up to this batch (see amenv_create)
 constexpr int kArmkAutoMax = 32768;   // AUTO: stage-wave arm kernel up to this batch (see amenv_create)
 
 namespace {
@@ -651,9 +652,11 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   }
   // lane-team kernel (16 lanes per env): one wavefront per SIMD up to 4096 envs; measured against the two-wave kernel on MI355X:
   // 4.9 vs 7.5 us at 2048 envs, 5.1 vs 7.6 at 4096, 7.5 vs 7.7 at 6144, 11.4 vs 7.8 at 8192 (a team workgroup is a main wave + an
-  // episode-end helper wave: above 4096 envs the SIMDs hold more than two waves) -> AUTO up to 6144 envs
+  // episode-end helper wave: above 4096 envs the SIMDs hold more than two waves) -> AUTO up to 6144 envs with the body-parallel RK4.  With the
+  // stage-parallel RK4 (tools/gpu_cross2.sh; against the stage-wave kernel): 4.69 vs 6.91 us at 4096 envs, 6.39 vs 6.96 at 5120, 6.64 vs 6.96 at 6144,
+  // 6.71 vs 7.01 at 7168, 6.81 vs 7.07 at 8192 (two main waves per SIMD), 10.3 vs 7.2 at 10240 -> AUTO up to 8192 envs
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes)
-    e->team = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 6144 : want == AMENV_KERNEL_TEAM;
+    e->team = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= kTeamAutoMax : want == AMENV_KERNEL_TEAM;
   // lane-quad kernel (4 lanes per env) for the rigid vehicles: fp32, 4 or 6 rotors, single-waypoint v2 task, default workgroup size
   const bool quad_ok = cfg->vehicle.n_joints == 0 && cfg->dtype == AMENV_F32 && (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) && !is_v1(cfg) &&
                        cfg->task.num_waypoints == 1 && cfg->block_size == 0;
@@ -676,7 +679,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // measured on MI355X (tools/gpu_armk.sh, gpu_armk2.sh): 7.0 vs 7.8 us (two-wave kernel) at 6400 envs, 7.4 vs 8.1 at 12288, 9.0 vs 10.2 at 24576, 9.3 vs
   // 10.6 at 32768; level from 36864 (10.6 vs 10.8) to 49152; a CU holds three of its workgroups (49 KB of LDS each), so above 49152 envs the
   // launch takes a second round of workgroups: 14.4 vs 11.8 us at 53248
-  e->armk = armk_ok && (want == AMENV_KERNEL_AUTO ? (cfg->num_envs > 6144 && cfg->num_envs <= kArmkAutoMax) : want == AMENV_KERNEL_STAGED);
+  e->armk = armk_ok && (want == AMENV_KERNEL_AUTO ? (cfg->num_envs > kTeamAutoMax && cfg->num_envs <= kArmkAutoMax) : want == AMENV_KERNEL_STAGED);
   if (want == AMENV_KERNEL_STAGED && !e->armk) {
     amenv_destroy(e);
     return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_STAGED is built for the fp32 6-rotor vehicle with the z,x,x arm, the single-waypoint v2 task "
@@ -856,9 +859,10 @@ int amenv_rollout_policy(amenv* e, int32_t n_steps, const float* flat_params, ui
     return AMENV_OK;
   }
   const TeamParams TP = make_team(*e);
-  // one 16-env workgroup per CU up to 4096 envs; above that two wavefronts per SIMD pay (measured on MI355X: 32768 envs)
+  // one 16-env workgroup per CU up to 4096 envs (5.15 vs 5.22 us per step there); above that the variant compiled for two wavefronts per SIMD pays
+  // (measured on MI355X at 8192 envs: 7.9 vs 10.1 us per step)
   const char* occ_env = std::getenv("AMENV_POLICY_OCC");   // bench / A-B only (tools/): 1 or 2
-  const int occ = occ_env ? std::atoi(occ_env) : (e->cfg.num_envs <= 8192 ? 1 : 2);
+  const int occ = occ_env ? std::atoi(occ_env) : (e->cfg.num_envs <= 4096 ? 1 : 2);
   if (occ == 1) hipLaunchKernelGGL((rollout_policy_kernel_team<6, 1>), dim3(e->n_tiles * 4), dim3(256), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io,
                                    e->stats, make_cold(*e), TP);
   else hipLaunchKernelGGL((rollout_policy_kernel_team<6, 2>), dim3(e->n_tiles * 4), dim3(256), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io, e->stats,

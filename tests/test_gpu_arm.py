@@ -367,7 +367,7 @@ def test_team_rollout_kernel_equals_team_steps():
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize("n,kernel", [(300, "team"), (4096, "team"), (1000, "lane"), (20000, "helper"), (20000, "auto")])
+@pytest.mark.parametrize("n,kernel", [(300, "team"), (4096, "team"), (6000, "auto"), (1000, "lane"), (20000, "helper"), (20000, "auto")])
 def test_closed_loop_policy_rollout_kernel(n, kernel):
     """amenv_rollout_policy: T closed-loop steps in one launch (bf16-MFMA actor / critic, Gaussian sampling, clip, env step) in its two
     forms: 16 lanes per env (where amenv_step runs the lane-team kernel) and one lane per env (64 or 128 envs per workgroup).
@@ -386,7 +386,7 @@ def test_closed_loop_policy_rollout_kernel(n, kernel):
             m.weight.mul_(30.0)
     env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel, max_episode_steps=60)
     ref = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="lane" if "armk" in env.kernel_name else kernel, max_episode_steps=60)
-    assert ("team" in env.kernel_name) == (kernel == "team") and ("armk" in env.kernel_name) == (kernel == "auto")
+    assert ("team" in env.kernel_name) == (kernel == "team" or (kernel == "auto" and n <= 8192)) and ("armk" in env.kernel_name) == (kernel == "auto" and n > 8192)
     o0 = env.reset().clone(); ref.reset()
     dev = env.device
     obs = torch.zeros(T + 1, n, 29, device=dev); acts = torch.zeros(T, n, 7, device=dev)
@@ -490,7 +490,7 @@ def test_arm_right_hand_side_device_code_vs_oracle(form):
     assert amd._lib.load().amenv_arm_rhs(C.byref(amd._lib.default_config("hexa", 1)), form, amd._lib.F64, p(ts), p(tw), p(tc), p(d), n, None) == -1
 
 
-@pytest.mark.parametrize("kernel,n", [("lane", 300), ("helper", 300), ("team", 300), ("auto", 8192)])
+@pytest.mark.parametrize("kernel,n", [("lane", 300), ("helper", 300), ("team", 300), ("auto", 12288)])
 @pytest.mark.parametrize("substeps", [2, 3])
 def test_arm_rk4_substeps_vs_oracle(substeps, kernel, n):
     """amenv_task.rk4_substeps > 1 (several RK4 steps of dt / substeps per control step) on every arm kernel that carries it, teacher-forced
