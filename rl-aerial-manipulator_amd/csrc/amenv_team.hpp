@@ -419,10 +419,10 @@ __device__ __forceinline__ void team_load(const char* tile, int i, const TeamLan
   E.step = iv.x; E.counter = iv.y; E.flags = iv.z; E.episode = iv.w;
 }
 
-// Two unconditional stores: (1) quad b writes group b (p|yaw, v|last_distance, q, w|return); (2) quad 0 the joint angles, quad 1 the
-// joint rates, quad 2 the int plane, quad 3 the waypoint group (rewritten with its unchanged value between resets) -- per-lane
-// offsets, no divergent store.
-__device__ __forceinline__ void team_store(char* tile, int i, const TeamLane& L, const TeamEnv& E) {
+// Two stores: (1) quad b writes group b (p|yaw, v|last_distance, q, w|return); (2) quad 0 the joint angles, quad 1 the joint rates, quad 2
+// the int plane, quad 3 the waypoint group -- per-lane offsets; the step kernel masks quad 3 off between resets (16 B per env-step of write
+// traffic; the rollout kernels store once per launch).
+__device__ __forceinline__ void team_store(char* tile, int i, const TeamLane& L, const TeamEnv& E, bool store_wp = true) {
   const uint32_t eoff = uint32_t(i & 63) * 16u + uint32_t(L.cc) * 4u;
   const bool l3 = L.cc == 3;
   const float g0 = l3 ? E.final_yaw : E.y.P, g1 = l3 ? E.last_distance : E.y.V, g3 = l3 ? E.ep_return : E.y.W;
@@ -431,7 +431,7 @@ __device__ __forceinline__ void team_store(char* tile, int i, const TeamLane& L,
   const int ival = L.cc == 0 ? E.step : (L.cc == 1 ? E.counter : (L.cc == 2 ? E.flags : E.episode));
   const float s2 = L.q0 ? E.y.TH : (L.q1 ? E.y.THD : (L.q2 ? __int_as_float(ival) : E.WP));
   const uint32_t off2 = L.q2 ? eoff : kIntBytes + (L.q0 ? 5u : (L.q1 ? 6u : 4u)) * 1024u + eoff;   // (the int plane has the same 16 B per env)
-  *reinterpret_cast<float*>(tile + off2) = s2;
+  if (L.q0 || L.q1 || L.q2 || store_wp) *reinterpret_cast<float*>(tile + off2) = s2;   // the waypoint group (quad 3) changes only at a reset (uniform within the row)
 }
 
 struct TeamOut { float reward; uint32_t bits; float vA, vB, vC; bool ended; int ep_len; float ep_ret; };
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(128) void step_kernel_team(void* __restrict__ blob,
     E.step = e.step; E.counter = e.counter; E.flags = e.flags; E.episode = e.episode;
   }
   AMENV_STAMP(5);          // barrier + reset values
-  team_store(tile, i, L, E);
+  team_store(tile, i, L, E, resets);
   team_store_outputs<false>(L, o, uint32_t(i), active, obs, reward_out, done, info);
   if (o.ended && active && tl.terminal_obs) {
     const uint32_t r0 = uint32_t(i) * OD;
