@@ -18,6 +18,12 @@
 //     with the SAME task_step / reset code as the one-lane kernels (amenv_model.hpp): every branch is uniform within a row, which is
 //     what keeps DPP legal inside it (DPP reads of EXEC-disabled lanes return 0).
 //
+//   * (round 2) what the four quads of a row are spent on inside the RK4 changed: the product build gives quad s RK4 STAGE s of the joint-
+//     configuration work (team_kin_stage: chain + three links, unmasked, aggregated to 14 registers) and evaluates the base dynamics on the
+//     aggregates (team_dyn_agg) -- see "Stage-parallel form" below; the body-parallel form described in the two points above (team_kin /
+//     team_dyn: quad b = body b, masked chain, sums over bodies per stage) is kept for A/B builds (-DAMENV_TEAM_BODY_PARALLEL).  Loads, stores,
+//     mixer, task step, reset and the helper wave are the same in both.
+//
 // Same model, same expressions as amenv_arm.hpp; sums are associated differently (trees over lanes), so results agree with the
 // one-lane kernel to rounding (tests: <= 2e-6 rel per step against the fp64 oracle, the same gate), not bit for bit.
 #pragma once
