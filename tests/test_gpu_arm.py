@@ -223,14 +223,18 @@ def test_two_wave_kernel_ragged_batches(n):
     assert bool(torch.isfinite(a[0]).all())
 
 
-def test_arm_long_run_stays_finite():
-    """1e8 env-steps of the headline configuration with random actions: no non-finite state, every episode ends by crash, bounds or time."""
+@pytest.mark.parametrize("vehicle,n,kernel,name", [("hexa_arm", 4096, "auto", "step_kernel_team"), ("hexa_arm", 16384, "auto", "step_kernel_armk"),
+                                                   ("hexa", 4096, "team", "step_kernel_quad")])
+def test_arm_long_run_stays_finite(vehicle, n, kernel, name):
+    """1e8 env-steps with random actions on the headline configuration (lane-team kernel), on the stage-wave kernel and on the lane-quad
+    rigid kernel: no non-finite state, every episode ends by crash, bounds or time."""
     import torch
     import rl_aerial_manipulator_amd as amd
-    env = amd.GpuWaypointEnv(4096, vehicle="hexa_arm", seed=1)
+    env = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=1, kernel=kernel)
+    assert name in env.kernel_name
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(3)
-    ring = torch.randn(64, 4096, 7, device="cuda", generator=g) * 0.5
+    ring = torch.randn(64, n, env.act_dim, device="cuda", generator=g) * 0.5
     ring[..., 0] += 1.0
     ring = ring.clamp(-1, 2).contiguous()
     graph = torch.cuda.CUDAGraph()
@@ -240,7 +244,7 @@ def test_arm_long_run_stays_finite():
     with torch.cuda.graph(graph):
         for t in range(64):
             env.step(ring[t])
-    for _ in range(24414 // 64):
+    for _ in range(100_000_000 // n // 64):
         graph.replay()
     torch.cuda.synchronize()
     s = env.stats()
