@@ -325,7 +325,7 @@ def main_worker(args):
             "note": f"{n} envs = {waves} wavefronts on 256 CUs (1024 SIMDs), {n * bytes_step / 1e6:.2f} MB algorithmic per launch"
                     + ("; latency-bound by construction at this batch: the launch is as long as one wave's instruction stream plus the ~1.7 us dependent-launch floor, "
                        "so the HBM fraction is small by design -- DESIGN.md section 6" if n <= 65536 else "")}
-        if not args.no_extras and rank == 0:
+        if not args.no_extras and rank == 0 and world == 1:   # single-GPU measurements; the N > 1 runs report the scaling line only
             out["extras"] = extras(args, amd, torch, env, ring, n, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         out["cpu_baseline"] = cpu_baseline(args, amd, n)
