@@ -16,6 +16,7 @@
 
 #include "amenv_kernels.hpp"
 #include "amenv_team.hpp"
+#include "amenv_team_host.hpp"
 #include "amenv_quad.hpp"
 #include "amenv_team_policy.hpp"
 #include "amenv_lane_policy.hpp"
@@ -42,7 +43,7 @@ struct amenv {
   bool arm2w = false;              // hexacopter + z,x,x arm at small batches: two-wave step kernel (amenv_kernels.hpp)
   bool pwave = false;              // rigid vehicles at small batches: second wave per tile computes the reset RNG words (step_kernel_pw)
   bool team = false;               // lane-team kernel (16 lanes per env): fp32 z,x,x-arm vehicle in the latency regime (amenv_team.hpp)
-  float* team_consts = nullptr;    // [kTeamConsts][16] per-lane constants of the team kernel
+  void* team_consts = nullptr;     // per-lane constants of the team kernels (amenv_team_host.hpp): float4 pieces, or plain doubles for the fp64 build
   bool team_ok = false;            // the configuration has a team kernel (fp32, 6 rotors, z,x,x arm): constants are allocated
   uint32_t* pol_pack = nullptr;    // amenv_rollout_policy: policy parameters as MFMA fragments (re-packed on every call)
   uint64_t steps = 0;
@@ -251,75 +252,9 @@ ArmParams<T> make_arm(const amenv& e) {
   return A;
 }
 
-// per-lane constant table of the team kernel: entry [k][4 * body + component] (amenv_team.hpp enum TeamConst)
-std::vector<float> team_const_table(const amenv_config& c) {
-  const amenv_vehicle& v = c.vehicle;
-  constexpr int NC4 = (kTeamConsts + 3) / 4;
-  std::vector<float> t(size_t(NC4) * 4 * 16, 0.0f);   // filled as [k][lane], re-packed below as float4 [k / 4][lane][k % 4]
-  double m_links = 0;
-  for (int k = 0; k < 3; k++) m_links += v.link_mass[k];
-  const float inv_pi = float(0.31830988618379067154);
-  for (int b = 0; b < 4; b++)
-    for (int cc = 0; cc < 4; cc++) {
-      const int l = 4 * b + cc;
-      auto set = [&](int k, double x) { t[size_t(k) * 16 + l] = float(x); };
-      const double* I = b == 0 ? v.inertia : &v.link_inertia[9 * (b - 1)];
-      set(TC_I00, I[0]); set(TC_I01, I[1]); set(TC_I02, I[2]); set(TC_I11, I[4]); set(TC_I12, I[5]); set(TC_I22, I[8]);
-      for (int j = 0; j < 3; j++) set(TC_LCX + j, b == 0 ? 0.0 : v.link_com[3 * (b - 1) + j]);
-      set(TC_MASS, b == 0 ? v.mass - m_links : v.link_mass[b - 1]);
-      for (int k = 0; k < 3; k++) { set(TC_MK0 + k, b > k ? 1.0 : 0.0); set(TC_E0 + k, cc == k ? 1.0 : 0.0); }
-      for (int r = 0; r < v.n_rotors && r < 6; r++) { set(TC_ALLOC0 + r, v.alloc[r * 4 + cc]); set(TC_MIX0 + r, v.mix[cc * v.n_rotors + r]); }
-      const double sp[4] = {.5, -.5, .5, -.5}, sq[4] = {.5, -.5, -.5, .5}, sr[4] = {.5, .5, -.5, -.5};
-      set(TC_SP, sp[cc]); set(TC_SQ, sq[cc]); set(TC_SR, sr[cc]);
-      t[size_t(TC_ACT1) * 16 + l] = cc == 0 ? float(v.mass) : float(v.moment_scale);
-      t[size_t(TC_ACT2) * 16 + l] = cc == 0 ? float(v.g) : 1.0f;
-      if (cc < 3) {
-        const float lo = float(v.joint_limit[2 * cc]), hi = float(v.joint_limit[2 * cc + 1]);
-        t[size_t(TC_JHALF) * 16 + l] = 0.5f * (hi - lo); t[size_t(TC_JMID) * 16 + l] = 0.5f * (hi + lo);
-        set(TC_O0, v.joint_origin[cc]);
-      }
-      set(TC_GV, cc == 2 ? -v.g : 0.0); set(TC_GV1, cc == 1 ? -v.g : 0.0); set(TC_GV2, cc == 0 ? -v.g : 0.0);
-      const float oa[4] = {0.1f, 0.2f, 1.0f, 0.2f}, ob[4] = {0.5f, 0.0f, inv_pi, inv_pi}, oc[4] = {0.2f, 2.0f, 0.0f, 0.0f};
-      t[size_t(TC_OBS_A) * 16 + l] = oa[b]; t[size_t(TC_OBS_B) * 16 + l] = ob[b]; t[size_t(TC_OBS_C) * 16 + l] = oc[b];
-    }
-  std::vector<float> packed(t.size(), 0.0f);
-  for (int k = 0; k < NC4 * 4; k++)
-    for (int l = 0; l < 16; l++) packed[(size_t(k / 4) * 16 + l) * 4 + k % 4] = t[size_t(k) * 16 + l];
-  return packed;
-}
-
-TeamParams make_team(const amenv& e) {
-  const amenv_config& c = e.cfg;
-  const amenv_vehicle& v = c.vehicle;
-  TeamParams P;
-  std::memset(&P, 0, sizeof(P));
-  for (int j = 0; j < 3; j++) {
-    P.o1[j] = float(v.joint_origin[3 + j]); P.o2[j] = float(v.joint_origin[6 + j]); P.tool[j] = float(v.tool_offset[j]);
-    P.ee_home[j] = float(v.joint_origin[j] + v.joint_origin[3 + j] + v.joint_origin[6 + j] + v.tool_offset[j]);
-  }
-  for (int k = 0; k < 3; k++) {
-    P.lm[k] = float(v.link_mass[k]);
-    for (int j = 0; j < 3; j++) P.lcm[k][j] = float(v.link_com[3 * k + j]);
-    const double* I = &v.link_inertia[9 * k];
-    const double six[6] = {I[0], I[1], I[2], I[4], I[5], I[8]};
-    for (int j = 0; j < 6; j++) P.li[k][j] = float(six[j]);
-  }
-  {
-    const double* I = v.inertia;
-    const double six[6] = {I[0], I[1], I[2], I[4], I[5], I[8]};
-    for (int j = 0; j < 6; j++) P.I0[j] = float(six[j]);
-  }
-  P.kp = float(v.joint_kp); P.kd = float(v.joint_kd); P.amax = float(v.joint_acc_max);
-  P.mtot = float(v.mass); P.inv_mtot = float(1.0 / v.mass); P.g = float(v.g);
-  const int ns = c.task.rk4_substeps > 0 ? c.task.rk4_substeps : 1;
-  P.h = float(c.task.dt / ns); P.substeps = ns;
-  for (int r = 0; r < 6; r++) { P.tmin[r] = float(v.t_min[r]); P.tmax[r] = float(v.t_max[r]); }
-  P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit; P.flags = c.flags;
-  P.ee_task = c.task.ee_task == AMENV_EE_TASK_TOOL ? 1 : 0;
-  P.K = 1;
-  P.consts = reinterpret_cast<const float4*>(e.team_consts);
-  return P;
-}
+// per-lane constant table / wave-uniform parameters of the team kernels: amenv_team_host.hpp (shared with the host emulation of tests/emu)
+std::vector<float> team_table_f32(const amenv_config& c) { return team_const_table<float>(c, true); }
+template <typename T> TeamParamsT<T> make_team(const amenv& e) { return make_team_params<T>(e.cfg, e.team_consts); }
 
 QuadParams make_quad(const amenv& e) {
   const amenv_config& c = e.cfg;
@@ -395,20 +330,26 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
   const StepTail tl{io.terminal_obs, io.ep_return, io.ep_len, io.stats};
   const uint32_t tb = e.tile_bytes;
   const int32_t n = e.cfg.num_envs;
-  if constexpr (NJ == 3 && sizeof(T) == 4) {
-    if (e.team) {    // 16 lanes per env, 4 envs per workgroup (step: main wave + episode-end helper wave; rollout: one wave)
+  if constexpr (NJ == 3) {
+    if (e.team) {    // 16 lanes per env, 4 envs per workgroup (step: main wave + episode-end helper wave; rollout: one wave); fp64 = logic-gate build, step only
       const dim3 g2(e.n_tiles * 16), b2(64), b2s(128);
-      const TeamParams TP = make_team(e);
+      const TeamParamsT<T> TP = make_team<T>(e);
       const float* act = reinterpret_cast<const float*>(io.actions);
       if (T_steps > 0) {
-        hipLaunchKernelGGL((rollout_kernel_team<NROT>), g2, b2, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, T_steps, tl, C, TP);
-        return hipGetLastError();
+        if constexpr (sizeof(T) == 4) {
+          hipLaunchKernelGGL((rollout_kernel_team<NROT>), g2, b2, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, T_steps, tl, C, TP);
+          return hipGetLastError();
+        } else {
+          return hipErrorInvalidValue;   // (amenv_rollout refuses the fp64 team build before it gets here)
+        }
       }
-      if (timed) hipExtLaunchKernelGGL((step_kernel_team<NROT>), g2, b2s, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done,
+      if (timed) hipExtLaunchKernelGGL((step_kernel_team<T, NROT>), g2, b2s, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, act, io.obs, static_cast<T*>(io.reward), io.done,
                                        io.info, tl, C, TP);
-      else hipLaunchKernelGGL((step_kernel_team<NROT>), g2, b2s, 0, s, e.blob, tb, n, act, io.obs, static_cast<float*>(io.reward), io.done, io.info, tl, C, TP);
+      else hipLaunchKernelGGL((step_kernel_team<T, NROT>), g2, b2s, 0, s, e.blob, tb, n, act, io.obs, static_cast<T*>(io.reward), io.done, io.info, tl, C, TP);
       return hipGetLastError();
     }
+  }
+  if constexpr (NJ == 3 && sizeof(T) == 4) {
     if (T_steps == 0 && e.armk) {    // one tile per 320-thread workgroup: four stage waves + main wave
       const dim3 g2(e.n_tiles), b2(320);
       const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + (4 * kAggSlots + 6 + 12) * 64) * sizeof(float);   // obs rows | aggregates | joints | reset words
@@ -657,6 +598,9 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // 6.71 vs 7.01 at 7168, 6.81 vs 7.07 at 8192 (two main waves per SIMD), 10.3 vs 7.2 at 10240 -> AUTO up to 8192 envs
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes)
     e->team = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= kTeamAutoMax : want == AMENV_KERNEL_TEAM;
+  // fp64 logic-gate build of the SAME kernel (DPP on register pairs): opt-in only, amenv_step only
+  if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F64 && cfg->vehicle.n_rotors == 6 && !make_arm<double>(*e).generic_axes && want == AMENV_KERNEL_TEAM)
+    e->team = true;
   // lane-quad kernel (4 lanes per env) for the rigid vehicles: fp32, 4 or 6 rotors, single-waypoint v2 task, default workgroup size
   const bool quad_ok = cfg->vehicle.n_joints == 0 && cfg->dtype == AMENV_F32 && (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) && !is_v1(cfg) &&
                        cfg->task.num_waypoints == 1 && cfg->block_size == 0;
@@ -668,7 +612,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   if (e->quadk) e->pwave = false;
   if (want == AMENV_KERNEL_TEAM && !e->team && !e->quadk) {
     amenv_destroy(e);
-    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is built for the fp32 6-rotor vehicle with the z,x,x arm (16 lanes per env) and for "
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_TEAM is built for the 6-rotor vehicle with the z,x,x arm (16 lanes per env; fp64 = logic-gate build) and for "
                 "fp32 rigid vehicles with 4 or 6 rotors, the single-waypoint v2 task and block_size = 0 (4 lanes per env)");
   }
   e->team_ok = cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes &&
@@ -687,7 +631,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   }
   if (e->team || e->armk) e->arm2w = false;
   if (e->quadk) {
-    const std::vector<float> tc = team_const_table(*cfg);
+    const std::vector<float> tc = team_table_f32(*cfg);
     if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(float))) != hipSuccess ||
         (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
       std::string msg = std::string("amenv_create: quad constants: ") + hipGetErrorString(s);
@@ -701,10 +645,19 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
       amenv_destroy(e);
       return fail(nullptr, AMENV_ERR_ALLOC, msg);
     }
-    const std::vector<float> tc = team_const_table(*cfg);
+    const std::vector<float> tc = team_table_f32(*cfg);
     if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(float))) != hipSuccess ||
         (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
       std::string msg = std::string("amenv_create: team constants: ") + hipGetErrorString(s);
+      amenv_destroy(e);
+      return fail(nullptr, AMENV_ERR_ALLOC, msg);
+    }
+  }
+  if (e->team && cfg->dtype == AMENV_F64) {
+    const std::vector<double> tc = team_const_table<double>(*cfg, false);
+    if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(double))) != hipSuccess ||
+        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+      std::string msg = std::string("amenv_create: team constants (fp64): ") + hipGetErrorString(s);
       amenv_destroy(e);
       return fail(nullptr, AMENV_ERR_ALLOC, msg);
     }
@@ -715,7 +668,8 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                               (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                               is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), is_v1(cfg) ? "v1" : "v2");
   else if (e->quadk) std::snprintf(buf, sizeof(buf), "step_kernel_quad<NROT=%d,v2> (4 lanes per env, 16 envs per wave + episode-end helper wave)", cfg->vehicle.n_rotors);
-  else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<NROT=6,v2+arm3> (16 lanes per env: 4 bodies x 4 components, 4 envs per wave + episode-end helper wave)");
+  else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<%s,NROT=6,v2+arm3> (16 lanes per env: 4 RK4 stages x 4 components, 4 envs per wave + episode-end helper wave)",
+                                  cfg->dtype == AMENV_F64 ? "double" : "float");
   else if (e->armk) std::snprintf(buf, sizeof(buf), "step_kernel_armk<float,NROT=6> block=320 (4 RK4 stage waves + main wave per 64-env tile)");
   else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
@@ -816,6 +770,7 @@ int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, v
   if (!e) return AMENV_ERR_INVALID;
   if (n_steps <= 0 || !actions) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: n_steps must be > 0 and actions non-NULL");
   if (!aligned16(actions) || (obs && !aligned16(obs))) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: actions/obs must be 16-byte aligned");
+  if (e->team && e->cfg.dtype == AMENV_F64) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: the fp64 lane-team build is a logic gate of amenv_step only");
   DeviceGuard g(e->device);
   StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, nullptr, nullptr, nullptr, e->stats};
   hipStream_t s = (hipStream_t)stream;
@@ -858,7 +813,7 @@ int amenv_rollout_policy(amenv* e, int32_t n_steps, const float* flat_params, ui
     e->steps += uint64_t(e->cfg.num_envs) * uint64_t(n_steps);
     return AMENV_OK;
   }
-  const TeamParams TP = make_team(*e);
+  const TeamParams TP = make_team<float>(*e);
   // one 16-env workgroup per CU up to 4096 envs (5.15 vs 5.22 us per step there); above that the variant compiled for two wavefronts per SIMD pays
   // (measured on MI355X at 8192 envs: 7.9 vs 10.1 us per step)
   const char* occ_env = std::getenv("AMENV_POLICY_OCC");   // bench / A-B only (tools/): 1 or 2

@@ -75,11 +75,11 @@ __device__ __forceinline__ void quad_store(char* tile, int i, const QuadLane& L,
 struct QuadDeriv { float V, Q, W; };
 
 // quadcopter.py:66-103 in component layout.  Fz = (F / m) e_z (thrust acceleration along body z), Mv = moments, I / J = inertia / inverse.
-__device__ __forceinline__ QuadDeriv quad_rhs(const float* c, const TM& I, const TM& J, float Q, float W, float Fz, float Mv) {
+__device__ __forceinline__ QuadDeriv quad_rhs(const float* c, const TM<float>& I, const TM<float>& J, float Q, float W, float Fz, float Mv) {
   QuadDeriv d;
   const float n2 = sum4(Q * Q);
   const float two_in2 = 2.0f * rcp_(n2);
-  const X3 qv{qp<1, 2, 3, 3>(Q), qp<2, 3, 1, 3>(Q), qp<3, 1, 2, 3>(Q)};
+  const X3<float> qv{qp<1, 2, 3, 3>(Q), qp<2, 3, 1, 3>(Q), qp<3, 1, 2, 3>(Q)};
   const float qw = bc<0>(Q);
   // world acceleration: Rq^T (F/m e_z) + (0, 0, -g) = A + (2/|q|^2) qv x (qv x A - qw A) + g      (:73-75)
   d.V = fma_(two_in2, cross_c(qv, fma_(-qw, Fz, cross_c(qv, Fz))), Fz) + c[TC_GV];
@@ -112,8 +112,8 @@ __device__ __forceinline__ QuadOut quad_advance(const QuadParams& P, const QuadL
   }
   const float Fz = (bc<0>(wr) * P.inv_mass) * c[TC_E2], Mv = qp<1, 2, 3, 3>(wr);
   const float e0 = c[TC_E0], e1 = c[TC_E1], e2 = c[TC_E2];
-  const TM I{fma_(e0, P.I[0], fma_(e1, P.I[1], e2 * P.I[2])), fma_(e0, P.I[1], fma_(e1, P.I[3], e2 * P.I[4])), fma_(e0, P.I[2], fma_(e1, P.I[4], e2 * P.I[5]))};
-  const TM J{fma_(e0, P.Iinv[0], fma_(e1, P.Iinv[1], e2 * P.Iinv[2])), fma_(e0, P.Iinv[1], fma_(e1, P.Iinv[3], e2 * P.Iinv[4])),
+  const TM<float> I{fma_(e0, P.I[0], fma_(e1, P.I[1], e2 * P.I[2])), fma_(e0, P.I[1], fma_(e1, P.I[3], e2 * P.I[4])), fma_(e0, P.I[2], fma_(e1, P.I[4], e2 * P.I[5]))};
+  const TM<float> J{fma_(e0, P.Iinv[0], fma_(e1, P.Iinv[1], e2 * P.Iinv[2])), fma_(e0, P.Iinv[1], fma_(e1, P.Iinv[3], e2 * P.Iinv[4])),
              fma_(e0, P.Iinv[2], fma_(e1, P.Iinv[4], e2 * P.Iinv[5]))};
   const float h = P.h, hh = 0.5f * h, h6 = h * (1.0f / 6.0f);
   int it = 0;

@@ -114,16 +114,6 @@ __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
-// observation values of the lane's three row segments for the state in registers (forward kinematics included)
-__device__ __forceinline__ void team_obs_vals(const TeamParams& P, const TeamLane& L, const TeamEnv& E, float eo, float& vA, float& vB, float& vC) {
-  const float* c = L.c;
-  const TeamState& z = E.y;
-  vA = (L.q0 ? z.P : (L.q1 ? z.V : (L.q2 ? z.Q : z.W))) * c[TC_OBS_A];
-  const float tp = P.ee_task != 0 ? z.P + eo : z.P;
-  vB = (L.q0 ? E.WP - tp : (L.q1 ? 0.0f : (L.q2 ? E.final_yaw : z.TH))) * c[TC_OBS_B];
-  vC = (L.q0 ? z.THD : eo) * c[TC_OBS_C];
-}
-
 // OCC = wavefronts per SIMD the register allocation leaves room for: 1 in the latency regime (one workgroup per CU: all 512 registers,
 // no spills), 2 in the throughput regime (<= 256 registers, a few spills, twice the resident wavefronts per SIMD).
 template <int NROT, int OCC>

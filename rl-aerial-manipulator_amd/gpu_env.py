@@ -175,6 +175,10 @@ class GpuWaypointEnv:
         want = {"obs": ((T + 1, n, self.obs_dim), torch.float32), "actions": ((T, n, self.act_dim), torch.float32), "logp": ((T, n), torch.float32),
                 "values": ((T, n), torch.float32), "rewards": ((T, n), torch.float32), "dones": ((T, n), torch.uint8)}
         got = {"obs": obs, "actions": actions, "logp": logp, "values": values, "rewards": rewards, "dones": dones}
+        if info_bits is not None:      # optional outputs are written [T,N] / [T,N,OD] by the kernel all the same: check them like the rest
+            want["info_bits"] = ((T, n), torch.int32); got["info_bits"] = info_bits
+        if terminal_obs is not None:
+            want["terminal_obs"] = ((T, n, self.obs_dim), torch.float32); got["terminal_obs"] = terminal_obs
         for k, (shape, dt) in want.items():
             t = got[k]
             if t.device != self.device or t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():

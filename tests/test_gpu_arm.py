@@ -36,6 +36,37 @@ def rand_actions(rng, n, scale=0.05):
     return a
 
 
+def test_team_fp64_build_rk4_substeps_and_ragged_batches():
+    """The fp64 lane-team build with RK4 sub-steps and batches that do not fill a tile: <= 1e-12 against the oracle, reset states bit-exact;
+    amenv_rollout refuses it (the build is a logic gate of amenv_step)."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    for n, sub in ((1, 1), (67, 2), (300, 3)):
+        rng = np.random.RandomState(n)
+        env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, dtype="f64", kernel="team", rk4_substeps=sub, max_episode_steps=40)
+        assert "step_kernel_team<double" in env.kernel_name
+        orc = orc_arm(n, seed=4)
+        orc.cfg.task.rk4_substeps = sub; orc.cfg.task.max_episode_steps = 40
+        env.reset()
+        f, i = gpu_state(env)
+        q = rng.normal(size=(4, n)) * 0.2; q[0] += 1; q /= np.linalg.norm(q, axis=0)
+        f[6:10] = q; f[10:13] = rng.normal(0, 1.0, (3, n)); f[19:22] = rng.uniform(-1, 1, (3, n)); f[22:25] = rng.normal(0, 1.0, (3, n))
+        env.set_state(f, i)
+        worst = 0.0
+        for t in range(60):
+            g, o = both_step(env, orc, rand_actions(rng, n))
+            f2, i2 = gpu_state(env)
+            assert np.array_equal(g["info"] & 127, o["info"] & 127) and np.array_equal(i2, orc.istate)
+            nd = o["done"] == 0
+            worst = max(worst, rel_err(f2[:, nd], orc.fstate[:, nd]).max() if nd.any() else 0.0)
+            assert np.array_equal(f2[:, ~nd], orc.fstate[:, ~nd])
+            np.testing.assert_allclose(g["reward"], o["reward"], rtol=1e-9, atol=1e-9)
+        assert worst < 1e-12, (n, sub, worst)
+        with pytest.raises(amd.AmenvError, match="logic gate"):
+            env.rollout(torch.zeros(2, n, 7, device="cuda"))
+        env.close()
+
+
 def test_arm_fp64_build_exists_and_uses_the_lane_kernel():
     """the fp64 logic-check build of the arm kernel (looped RK4: one copy of the RHS, no scratch)."""
     import rl_aerial_manipulator_amd as amd
@@ -67,7 +98,8 @@ def test_arm_dims_and_reset():
 
 # fp32 vs fp64 oracle: rounding level, far inside the 1e-5 gate; fp64 build: the logic gate; "team" = the lane-team kernel (16 lanes per env),
 # "staged" = the stage-wave kernel (four RK4 stage waves + main wave per tile, base dynamics on joint-configuration aggregates)
-@pytest.mark.parametrize("dtype,tol,kernel", [("f32", 2e-6, "lane"), ("f32", 2e-6, "helper"), ("f32", 3e-6, "team"), ("f32", 3e-6, "staged"), ("f64", 1e-12, "lane")])
+@pytest.mark.parametrize("dtype,tol,kernel", [("f32", 2e-6, "lane"), ("f32", 2e-6, "helper"), ("f32", 3e-6, "team"), ("f32", 3e-6, "staged"), ("f64", 1e-12, "lane"),
+                                               ("f64", 1e-12, "team")])   # fp64 build of the lane-team kernel: the logic gate of its DPP plumbing (selectors, row sums, stage hand-over)
 def test_arm_closed_loop_vs_oracle(dtype, tol, kernel):
     """Teacher-forced per step (the oracle is re-seated on the GPU state each step), joints slewing, with resets."""
     import rl_aerial_manipulator_amd as amd

@@ -1,0 +1,104 @@
+"""The lane-team kernels' arithmetic on the CPU: csrc/amenv_team_math.hpp -- the SAME source the HIP kernels instantiate for float and
+double -- compiled with g++ for a 16-lane host vector (tests/emu/team_emu.cpp: DPP quad_perm / row_ror / row_shr as array permutations)
+and compared with the fp64 oracle.  This is the CPU-side logic gate of the round-3 formulation: gravity-free angular chain (Euler's
+equation about the system CoM), the [w]x (2 J - tr J) identity, the systolic stage hand-over between the quads of a row, the per-stage
+translational accelerations and the weighted row sums.  A wrong selector, hand-over direction, RK4 weight or mis-associated row sum fails
+here; the device code itself is gated on the GPU (tests/test_gpu_arm.py: fp64 build <= 1e-12)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.test_arm_cpu import arm_cfg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "emu", "team_emu.cpp")
+LIB = os.path.join(HERE, "emu", "libteam_emu.so")
+DEPS = [SRC] + [os.path.join(HERE, "..", "rl-aerial-manipulator_amd", "csrc", f) for f in ("amenv_team_math.hpp", "amenv_team_host.hpp")] + [os.path.join(HERE, "..", "include", "amenv.h")]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in DEPS):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", "-o", LIB, SRC])
+    L = C.CDLL(LIB)
+    L.team_emu_step.argtypes = [C.POINTER(O.Config), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def random_states(rng, n):
+    s = np.zeros((n, 19))
+    s[:, 0:3] = rng.uniform(-2, 2, (n, 3)); s[:, 3:6] = rng.normal(0, 1.5, (n, 3))
+    q = rng.normal(size=(n, 4)); s[:, 6:10] = q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.98, 1.02, (n, 1))
+    s[:, 10:13] = rng.normal(0, 2.0, (n, 3)); s[:, 13:16] = rng.uniform(-1.5, 1.5, (n, 3)); s[:, 16:19] = rng.normal(0, 2.0, (n, 3))
+    a = rng.uniform(-1, 1, (n, 7)).astype(np.float32); a[:, 0] = rng.uniform(0, 2, n)
+    a[::3, 4:] *= 0.02          # two thirds of the joint commands saturate the servos, one third stays inside
+    return s, a
+
+
+def emu_step(emu, cfg, s, a, probe=False):
+    n = len(s)
+    out = s.copy(); eo = np.zeros((n, 3)); qc = np.zeros(n); pr = np.zeros((n, 4, 13))
+    assert emu.team_emu_step(C.byref(cfg), out.ctypes.data, a.ctypes.data, n, eo.ctypes.data, pr.ctypes.data if probe else None, qc.ctypes.data) == 0
+    return out, eo, qc, pr
+
+
+@pytest.mark.parametrize("substeps", [1, 3])
+def test_team_formulation_equals_the_oracle_step(emu, substeps):
+    cfg = arm_cfg()
+    cfg.task.rk4_substeps = substeps
+    s, a = random_states(np.random.RandomState(substeps), 1024)
+    out, eo, qc, _ = emu_step(emu, cfg, s, a)
+    ref = np.stack([O.arm_dynamics_step(cfg, s[i], a[i])[0] for i in range(len(s))])
+    err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-13, err.max(0)
+    eo_ref = np.stack([O.ee_position(cfg, ref[i]) - ref[i, :3] for i in range(len(s))])
+    assert np.abs(eo - eo_ref).max() < 1e-14
+    # the replicated base state must stay BIT-IDENTICAL in the four quads of a row (sum_bodies associates the same way in all of them)
+    assert qc.max() == 0.0
+
+
+def test_each_quad_holds_its_own_rk4_stage(emu):
+    """After the four systolic rounds quad s holds stage s's state and derivatives: compared stage by stage with the oracle's right-hand
+    side along its own RK4 (a wrong hand-over direction / coefficient or a stale stage state shows up in the stage it corrupts)."""
+    cfg = arm_cfg()
+    s, a = random_states(np.random.RandomState(7), 256)
+    _, _, _, pr = emu_step(emu, cfg, s, a, probe=True)
+    h = cfg.task.dt
+    worst = 0.0
+    for i in range(len(s)):
+        _, w = O.arm_dynamics_step(cfg, s[i], a[i])        # wrench_out: F, M(3), joint commands(3)
+        F, M, cmd = w[0], w[1:4], w[4:7]
+        y = s[i].copy(); ks = []
+        for st, c in enumerate((0.0, 0.5, 0.5, 1.0)):
+            y = s[i] + c * h * ks[-1] if ks else s[i].copy()
+            k = O.arm_rhs(cfg, y, F, M, cmd)
+            ks.append(k)
+            got = pr[i, st]
+            ref = np.r_[k[3:6], k[6:10], k[10:13], y[10:13]]
+            worst = max(worst, (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+    assert worst < 1e-12, worst
+
+
+def test_rigid_limit_and_heavy_arm(emu):
+    """Parameter sweeps the default vehicle does not reach: massless links (== rigid hexacopter dynamics of the base) and links ten times
+    heavier with off-diagonal inertias everywhere (every term of the aggregates carries weight)."""
+    rng = np.random.RandomState(11)
+    s, a = random_states(rng, 256)
+    cfg = arm_cfg()
+    for k in range(3):
+        cfg.vehicle.link_mass[k] *= 10.0
+        I = np.array(cfg.vehicle.link_inertia[9 * k:9 * k + 9]).reshape(3, 3) * 10.0
+        Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        I = Q @ I @ Q.T
+        for j in range(9):
+            cfg.vehicle.link_inertia[9 * k + j] = I.reshape(-1)[j]
+        for j in range(3):
+            cfg.vehicle.link_com[3 * k + j] += rng.normal() * 0.02
+    cfg.vehicle.mass = cfg.vehicle.mass + 9.0 * (0.082 + 0.054 + 0.220)
+    out, _, qc, _ = emu_step(emu, cfg, s, a)
+    ref = np.stack([O.arm_dynamics_step(cfg, s[i], a[i])[0] for i in range(len(s))])
+    assert (np.abs(out - ref) / np.maximum(1.0, np.abs(ref))).max() < 1e-12 and qc.max() == 0.0
