@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libamenv.so")
 SOURCES = ["amenv_capi.hip"]
-DEPS = ["amenv_capi.hip", "amenv_kernels.hpp", "amenv_team.hpp", "amenv_quad.hpp", "amenv_team_policy.hpp", "amenv_lane_policy.hpp", "amenv_model.hpp", "amenv_arm.hpp", "amenv_obsnorm.hpp", "amenv_train.hpp", "amenv_mlp_train.hpp", "amenv_policy.hpp", "amenv_baseline.hpp", os.path.join("..", "..", "include", "amenv.h")]
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [os.path.join("..", "..", "include", "amenv.h")]   # every source of the one translation unit
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          # episode-end code adds its own lane's numbers with plain no-return atomics (usually ONE lane is active): the wave-reduction
          # the compiler would wrap around same-address atomics is a hundred instructions on a path whose cost is its instruction count

@@ -255,6 +255,11 @@ ArmParams<T> make_arm(const amenv& e) {
 // per-lane constant table / wave-uniform parameters of the team kernels: amenv_team_host.hpp (shared with the host emulation of tests/emu)
 std::vector<float> team_table_f32(const amenv_config& c) { return team_const_table<float>(c, true); }
 template <typename T> TeamParamsT<T> make_team(const amenv& e) { return make_team_params<T>(e.cfg, e.team_consts); }
+// the device copy of the parameters behind the per-lane table (the step kernel's source; the other team kernels take them as arguments)
+template <typename T> hipError_t team_write_params(amenv* e) {
+  const TeamParamsT<T> P = make_team<T>(*e);
+  return hipMemcpy(static_cast<char*>(e->team_consts) + team_table_bytes<T>(), &P, sizeof(P), hipMemcpyHostToDevice);
+}
 
 QuadParams make_quad(const amenv& e) {
   const amenv_config& c = e.cfg;
@@ -343,9 +348,10 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
           return hipErrorInvalidValue;   // (amenv_rollout refuses the fp64 team build before it gets here)
         }
       }
-      if (timed) hipExtLaunchKernelGGL((step_kernel_team<T, NROT>), g2, b2s, 0, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, act, io.obs, static_cast<T*>(io.reward), io.done,
-                                       io.info, tl, C, TP);
-      else hipLaunchKernelGGL((step_kernel_team<T, NROT>), g2, b2s, 0, s, e.blob, tb, n, act, io.obs, static_cast<T*>(io.reward), io.done, io.info, tl, C, TP);
+      const int32_t nb = int32_t(g2.x);   // (the step kernel reads its parameters from the device block behind the table: amenv_create wrote them there)
+      if (timed) hipExtLaunchKernelGGL((step_kernel_team<T, NROT>), g2, b2s, 0, s, e.ev_start, e.ev_stop, 0, e.blob, n, nb, act, TP.consts, io.obs, static_cast<T*>(io.reward), io.done,
+                                       io.info, tl, C);
+      else hipLaunchKernelGGL((step_kernel_team<T, NROT>), g2, b2s, 0, s, e.blob, n, nb, act, TP.consts, io.obs, static_cast<T*>(io.reward), io.done, io.info, tl, C);
       return hipGetLastError();
     }
   }
@@ -646,8 +652,9 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
       return fail(nullptr, AMENV_ERR_ALLOC, msg);
     }
     const std::vector<float> tc = team_table_f32(*cfg);
-    if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(float))) != hipSuccess ||
-        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
+    if ((s = hipMalloc((void**)&e->team_consts, team_block_bytes<float>())) != hipSuccess ||
+        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+        (s = team_write_params<float>(e)) != hipSuccess) {
       std::string msg = std::string("amenv_create: team constants: ") + hipGetErrorString(s);
       amenv_destroy(e);
       return fail(nullptr, AMENV_ERR_ALLOC, msg);
@@ -655,8 +662,9 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   }
   if (e->team && cfg->dtype == AMENV_F64) {
     const std::vector<double> tc = team_const_table<double>(*cfg, false);
-    if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(double))) != hipSuccess ||
-        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) {
+    if ((s = hipMalloc((void**)&e->team_consts, team_block_bytes<double>())) != hipSuccess ||
+        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (s = team_write_params<double>(e)) != hipSuccess) {
       std::string msg = std::string("amenv_create: team constants (fp64): ") + hipGetErrorString(s);
       amenv_destroy(e);
       return fail(nullptr, AMENV_ERR_ALLOC, msg);

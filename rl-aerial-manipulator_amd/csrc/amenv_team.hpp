@@ -88,24 +88,26 @@ struct TeamLaneT {
   uint32_t offA, offB, offC;                     // observation columns this lane writes in the three row segments
   bool okA, okB, okC;
   X c[((kTeamConsts + 3) / 4) * 4];              // this lane's constants
-  __device__ __forceinline__ void init(const TeamParamsT<X>& P) {
+  __device__ __forceinline__ void init(const TeamParamsT<X>& P) { init(P.consts); }
+  __device__ __forceinline__ void init(const void* table) {
     lane = int(threadIdx.x) & 63; cc = lane & 3; bb = (lane >> 2) & 3;
     q0 = bb == 0; q1 = bb == 1; q2 = bb == 2; lead = (lane & 15) == 0;
     // A = [p/10 | v/5 | q | w/5] by quad, B = [(wp - task point)/2 | 0 | yaw/pi | th/pi], C = [thd/5 | tool offset*2]
-    offA = q0 ? cc : (q1 ? 3 + cc : (q2 ? 6 + cc : 10 + cc));
-    offB = q0 ? 13 + cc : (q1 ? 16 + cc : (q2 ? 19 : 20 + cc));
-    offC = q0 ? 23 + cc : 26 + cc;
+    // (arithmetic, not nested selects: the compiler turned those into EXEC-masked branches in front of the first load)
+    offA = uint32_t(cc + 3 * bb + (bb == 3 ? 1 : 0));                       // 0 + c | 3 + c | 6 + c | 10 + c
+    offB = uint32_t(13 + 3 * bb - (bb == 3 ? 2 : 0) + (q2 ? 0 : cc));       // 13 + c | 16 + c | 19 | 20 + c
+    offC = uint32_t(23 + cc + (bb > 0 ? 3 : 0));                            // 23 + c | 26 + c
     okA = cc < 3 || q2; okB = q2 ? cc == 0 : cc < 3; okC = cc < 3 && bb < 2;
     constexpr int NC4 = (kTeamConsts + 3) / 4;
     if constexpr (sizeof(X) == 4) {              // float4 pieces [k / 4][lane][k % 4]
-      const float4* tab = static_cast<const float4*>(P.consts);
+      const float4* tab = static_cast<const float4*>(table);
 #pragma unroll
       for (int k = 0; k < NC4; k++) {
         const float4 v = tab[k * 16 + (lane & 15)];
         c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
       }
     } else {                                     // [k][lane]
-      const X* tab = static_cast<const X*>(P.consts);
+      const X* tab = static_cast<const X*>(table);
 #pragma unroll
       for (int k = 0; k < NC4 * 4; k++) c[k] = tab[k * 16 + (lane & 15)];
     }
@@ -116,15 +118,23 @@ using TeamLane = TeamLaneT<float>;
 // state of env i from its tile: lane c of every quad reads component c of each group; the per-env scalars ride in slot 3 of the
 // p / v / w groups
 template <typename X>
-__device__ __forceinline__ void team_load(const char* tile, int i, const TeamLaneT<X>& L, TeamEnvT<X>& E) {
+__device__ __forceinline__ void team_load_issue(const char* tile, int i, const TeamLaneT<X>& L, TeamEnvT<X>& E) {   // the loads only
   constexpr uint32_t GB = 64u * 4u * sizeof(X);
   const uint32_t eoff = (uint32_t(i & 63) * 4u + uint32_t(L.cc)) * uint32_t(sizeof(X));
   auto gload = [&](int g) { return *reinterpret_cast<const X*>(tile + kIntBytes + uint32_t(g) * GB + eoff); };
   E.y = TeamStateT<X>{gload(0), gload(1), gload(2), gload(3), gload(5), gload(6)};
   E.WP = gload(4);
   const int4 iv = *(reinterpret_cast<const int4*>(tile) + (i & 63));
-  E.final_yaw = bc<3>(E.y.P); E.last_distance = bc<3>(E.y.V); E.ep_return = bc<3>(E.y.W);
   E.step = iv.x; E.counter = iv.y; E.flags = iv.z; E.episode = iv.w;
+}
+template <typename X>
+__device__ __forceinline__ void team_load_unpack(TeamEnvT<X>& E) {   // the per-env scalars out of slot 3 (first use of the loaded data)
+  E.final_yaw = bc<3>(E.y.P); E.last_distance = bc<3>(E.y.V); E.ep_return = bc<3>(E.y.W);
+}
+template <typename X>
+__device__ __forceinline__ void team_load(const char* tile, int i, const TeamLaneT<X>& L, TeamEnvT<X>& E) {
+  team_load_issue(tile, i, L, E);
+  team_load_unpack(E);
 }
 
 // Two stores: (1) quad b writes group b (p|yaw, v|last_distance, q, w|return); (2) quad 0 the joint angles, quad 1 the joint rates, quad 2
@@ -218,7 +228,11 @@ __device__ __forceinline__ TeamOutT<X> team_advance(const TeamParamsT<X>& P, con
                                                     float* terminal_obs, float* ep_return_out, int32_t* ep_len_out) {
   constexpr int OD = 29;
   TeamStateT<X>& y = E.y;
-  const X EO = team_dynamics<NROT>(P, L.c, L.q0, L.q1, L.q2, y, act, actj);
+#ifdef AMENV_TEAM_DIAG_NORK4   // diagnostic build: what the launch costs without the arithmetic (tools/build_variant.py)
+  const X EO = y.TH + act * actj;
+#else
+  const X EO = team_dynamics(P, L.c, L.q0, L.q1, L.q2, y, act, actj);
+#endif
   // ---- task step: the one-lane kernels' code on broadcast copies of the state (identical in the 16 lanes of a row)
   Env<X, 1> e;
   e.px = bc<0>(y.P); e.py = bc<1>(y.P); e.pz = bc<2>(y.P);
@@ -276,6 +290,20 @@ __device__ __forceinline__ void team_store_outputs(const TeamLaneT<X>& L, const 
   }
 }
 
+// "This wave reads these registers here": an empty asm per value.  The helper wave of the step kernel starts with it, so that the loads both
+// waves issue in front of the role branch stay there -- the compiler otherwise sinks every load only the main wave consumes into the main
+// wave's branch, behind that branch's own (second) batch of kernel-argument loads.
+template <typename X> __device__ __forceinline__ void team_touch(X v) {
+  if constexpr (sizeof(X) == 4) asm volatile("" ::"v"(v));
+  else asm volatile("" ::"v"(__double2loint(v)), "v"(__double2hiint(v)));
+}
+
+// "These kernel arguments are read here": an empty asm per wave-uniform value.  The step kernel starts with the arguments its first vector
+// loads need, so that they arrive in ONE batch of scalar loads issued at wave start; left to itself the compiler batches arguments by
+// basic block, and every batch in front of the first vector load is a full (dependent) trip to the kernel-argument segment.
+template <typename A> __device__ __forceinline__ void team_arg(A a) { asm volatile("" ::"s"(a)); }
+template <typename A, typename... R> __device__ __forceinline__ void team_arg(A a, R... r) { team_arg(a); team_arg(r...); }
+
 // raw buffer descriptor over [p, p + bytes): a store whose byte offset is >= bytes is dropped by the hardware -- lanes (and rows past the
 // last env) are masked by their OFFSET instead of by EXEC, so the store tail of the step kernel has no branches
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t team_rsrc(void* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, int(bytes), 0x00020000); }
@@ -292,10 +320,25 @@ constexpr uint32_t kOob = 0xFFFFFFFFu;
 // episode in this step -- a conservative test on the loaded state (time limit: exact; hold counter at its limit; height / range within one
 // step's travel of the crash / bounds thresholds).  A row that ends without having been announced (no such case is known) is reset by the
 // main wave itself, so the test only decides who does the work, never the result.  The totals replica is read only when an episode ended.
+// The first 8 dwords of the arguments are what the first loads need; the tile size is a constant of this kernel (one waypoint group, two joint groups).
+#ifndef AMENV_TEAM_STEP_ATTR
+#define AMENV_TEAM_STEP_ATTR
+#endif
 template <typename X, int NROT>
-__global__ __launch_bounds__(128) void step_kernel_team(void* __restrict__ blob, uint32_t tile_bytes, int32_t n_envs, const float* __restrict__ actions,
-                                                        float* __restrict__ obs, X* __restrict__ reward_out, uint8_t* __restrict__ done,
-                                                        uint32_t* __restrict__ info, const StepTail tl, const ColdParams C, const TeamParamsT<X> P) {
+__global__ __launch_bounds__(128) AMENV_TEAM_STEP_ATTR void step_kernel_team(void* __restrict__ blob, int32_t n_envs, int32_t n_blocks, const float* __restrict__ actions,
+                                                        const void* __restrict__ lane_consts, float* __restrict__ obs, X* __restrict__ reward_out,
+                                                        uint8_t* __restrict__ done, uint32_t* __restrict__ info, const StepTail tl, const ColdParams C) {
+  constexpr uint32_t tile_bytes = kIntBytes + 7u * 64u * 4u * uint32_t(sizeof(X));
+  // wave-uniform parameters: scalar loads from the device block behind the per-lane table (see team_block_bytes)
+  TeamParamsT<X> P;
+  {
+    typedef const __attribute__((address_space(4))) uint32_t ConstWord;   // constant address space: uniform loads from it are scalar loads
+    ConstWord* src = (ConstWord*)(static_cast<const char*>(lane_consts) + team_table_bytes<X>());
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&P);
+    static_assert(sizeof(TeamParamsT<X>) % 4 == 0, "copied word by word");
+#pragma unroll
+    for (int k = 0; k < int(sizeof(TeamParamsT<X>) / 4); k++) dst[k] = src[k];
+  }
   static_assert(NROT == 6, "team kernel: 6-rotor airframe");
   constexpr int AD = 7, OD = 29;
   __shared__ X rst[6][64];                         // team_reset's values, lane for lane
@@ -306,43 +349,70 @@ __global__ __launch_bounds__(128) void step_kernel_team(void* __restrict__ blob,
   unsigned long long stamps_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+  team_arg(blob, n_envs, n_blocks, actions, lane_consts);   // what the first loads need: ONE small batch of argument loads, nothing else in front of it
+  AMENV_STAMP(0);
+  // Both waves of the workgroup start the same way -- constants, state, actions: ONE batch of kernel-argument loads and the vector loads
+  // right behind it (with the role branch first, the main wave's arguments arrived in a second, dependent batch: +370 clocks before its
+  // first load was issued).  The helper needs the state for its episode-end test anyway; its copies of the lines come from the L1 / L2.
   TeamLaneT<X> L;
-  const int lane0 = int(threadIdx.x) & 63;
-  const int row = lane0 >> 4;
-  const int i0 = team_group_of_block(int(blockIdx.x), int(gridDim.x)) * 4;   // first env of this workgroup (wave-uniform; its 4 envs share a tile)
+  L.init(lane_consts);
+  const int row = L.lane >> 4;
+  const int i0 = team_group_of_block(int(blockIdx.x), n_blocks) * 4;   // first env of this workgroup (wave-uniform; its 4 envs share a tile)
   const int i = i0 + row;                                                    // env of this row
   const bool active = i < n_envs;
   char* tile = static_cast<char*>(blob) + size_t(i0 >> 6) * tile_bytes;
+  const int ia = active ? i : n_envs - 1;                   // rows past the end redo the last env's arithmetic (their outputs are masked)
+  TeamEnvT<X> E;
+  team_load_issue(tile, i, L, E);
+  const float act_f = actions[size_t(ia) * AD + L.cc];                                    // a0..a3: one per lane
+  const float actj_f = actions[size_t(ia) * AD + 4 + (L.cc < 3 ? L.cc : 2)];               // joint commands a4..a6
+#ifdef AMENV_TEAM_DIAG_NOHELPER   // diagnostic build: the helper wave leaves at once (no episode-end service: timing only)
+  if (role == 1) { __syncthreads(); return; }
+#endif
   if (role == 1) {
-    L.lane = lane0; L.cc = lane0 & 3; L.bb = (lane0 >> 2) & 3;
-    L.q0 = L.bb == 0; L.q1 = L.bb == 1; L.q2 = L.bb == 2; L.lead = (lane0 & 15) == 0;
-    const bool owned = gridDim.x <= kStatsReplicas;   // wave-uniform
+    // (the helper "reads" everything the main wave loaded -- see team_touch -- and drops it at once: its own work needs few registers)
+#pragma unroll
+    for (int k = 0; k < kTeamConsts; k++)
+      if (k < TC_ALLOC0 || k >= TC_GV1) team_touch(L.c[k]);
+    team_touch(E.y.Q); team_touch(E.y.W); team_touch(E.y.TH); team_touch(E.y.THD); team_touch(E.WP); team_touch(act_f); team_touch(actj_f);
+    const bool owned = n_blocks <= kStatsReplicas;   // wave-uniform
     if (L.lane < S_COUNT) acc[L.lane] = 0ull;
-    // can this row's episode end in this step?
-    constexpr uint32_t GB = 64u * 4u * sizeof(X);
-    const uint32_t eoff = (uint32_t(i & 63) * 4u + uint32_t(L.cc)) * uint32_t(sizeof(X));
-    const X Pc = *reinterpret_cast<const X*>(tile + kIntBytes + eoff), Vc = *reinterpret_cast<const X*>(tile + kIntBytes + GB + eoff);
-    const int4 iv = *(reinterpret_cast<const int4*>(tile) + (i & 63));
+    // Can this row's episode end in this step?  Lane-local tests + one ballot (the helper shares its SIMD with an integrating wave: no DPP,
+    // no square roots here): time limit (exact); hold counter at its limit; height within one step's travel of the crash threshold (lane z);
+    // some coordinate beyond 10 / sqrt(3) after one step's travel (|p| > 10 needs one).  NaNs compare "may".
     const X dtc = P.h * X(P.substeps), slack = X(0.01) + X(50) * dtc * dtc;   // one step's travel beyond |v| dt: accelerations up to 100 m/s^2
-    const X pz = bc<2>(Pc), vz = bc<2>(Vc);
-    const X pn = sqrt_(bc<0>(dot3(Pc, Pc))), vn = sqrt_(bc<0>(dot3(Vc, Vc)));
-    const bool may = iv.x >= P.max_steps || ((iv.z & AMENV_FLAGBIT_FWR) && iv.y >= P.counter_limit) || !(pz - dtc * abs_(vz) - slack > X(0.1)) ||
-                     !(pn + dtc * vn + slack < X(10)) || (P.flags & AMENV_FLAG_NAN_GUARD);
+    const X reach = fma_(dtc, abs_(E.y.V), abs_(E.y.P)) + slack;              // lanes 0..2 (lane 3 carries the per-env scalars: excluded below)
+    const bool lane_may = (L.cc < 3 && !(reach < X(5.7735))) || (L.cc == 2 && !(E.y.P - dtc * abs_(E.y.V) - slack > X(0.1)));
+    const unsigned long long mm = __ballot(lane_may);
+    const bool may = ((mm >> (L.lane & 48)) & 0xFFFFull) != 0ull || E.step >= P.max_steps || ((E.flags & AMENV_FLAGBIT_FWR) && E.counter >= P.counter_limit) ||
+                     (P.flags & AMENV_FLAG_NAN_GUARD);
+#ifdef AMENV_TEAM_DIAG_NOPREDICT   // diagnostic build: the helper never prepares a reset (the main wave computes it inline): timing only
+    const bool may_ = may; (void)may_;
+#define may false
+#endif
     if (L.lead) have[row] = may ? 1u : 0u;
+    unsigned long long* totals = tl.stats + size_t(blockIdx.x & (kStatsReplicas - 1)) * kStatsStride;
+    unsigned long long mine = 0ull;
+    bool fetched = false;                           // wave-uniform
     if (__ballot(may) != 0ull) {   // wave-uniform; rows are uniform, DPP stays inside quads
-      L.init(P);
+      if (owned && L.lane < S_COUNT) mine = totals[L.lane];   // an episode end is likely: the replica's line, in flight during the barrier
+      fetched = true;
       if (may) {
-        const TeamResetT<X> R = team_reset(P, C, L, iv.w, i);
+        const TeamResetT<X> R = team_reset(P, C, L, E.episode, i);
         rst[0][L.lane] = R.P; rst[1][L.lane] = R.WP; rst[2][L.lane] = R.final_yaw;
         rst[3][L.lane] = R.vA; rst[4][L.lane] = R.vB; rst[5][L.lane] = R.vC;
       }
     }
+#ifdef AMENV_TEAM_DIAG_NOPREDICT
+#undef may
+#endif
     __syncthreads();
+#ifdef AMENV_TEAM_DIAG_NOPOST   // diagnostic build: the helper leaves after the barrier (no Monitor service: timing only)
+    return;
+#endif
     const bool ended = (fl[row][0] & 1u) != 0 && L.lead;   // one lane per ended row
     if (__ballot(ended) != 0ull) {   // wave-uniform
-      unsigned long long* totals = tl.stats + size_t(blockIdx.x & (kStatsReplicas - 1)) * kStatsStride;
-      unsigned long long mine = 0ull;
-      if (owned && L.lane < S_COUNT) mine = totals[L.lane];
+      if (!fetched && owned && L.lane < S_COUNT) mine = totals[L.lane];
       if (ended) {
         const uint32_t bits = fl[row][1];
         const int ep_len = int(fl[row][2]);
@@ -360,21 +430,18 @@ __global__ __launch_bounds__(128) void step_kernel_team(void* __restrict__ blob,
     }
     return;
   }
-  AMENV_STAMP(0);
-  L.init(P);
-  const int ia = active ? i : n_envs - 1;                   // rows past the end redo the last env's arithmetic (their outputs are masked)
-  TeamEnvT<X> E;
-  team_load(tile, i, L, E);
-  const X act = X(actions[size_t(ia) * AD + L.cc]);                                       // a0..a3: one per lane
-  const X actj = X(actions[size_t(ia) * AD + 4 + (L.cc < 3 ? L.cc : 2)]);                  // joint commands a4..a6
-  // store plumbing, formed while the loads are in flight: byte offsets, out of range where this lane (or a row past the last env) does not store
+#ifndef AMENV_TEAM_DIAG_NOPRIO
+  __builtin_amdgcn_s_setprio(3);   // every SIMD also holds some workgroup's helper wave: the integrating wave goes first whenever both can issue
+#endif
+  team_load_unpack(E);
+  const X act = X(act_f), actj = X(actj_f);
+  // store plumbing, formed while the loads are in flight (pinned there: the scheduler would otherwise sink it into the tail, which the
+  // launch waits for): byte offsets into the observation rows, out of range where this lane -- or a row past the last env -- does not store
   const uint32_t obs_bytes = uint32_t(n_envs) * uint32_t(OD * 4);
   const uint32_t rowb = uint32_t(i) * uint32_t(OD * 4);
-  const uint32_t voA = L.okA ? rowb + L.offA * 4u : kOob, voB = L.okB ? rowb + L.offB * 4u : kOob, voC = L.okC ? rowb + L.offC * 4u : kOob;
-  const uint32_t vo1 = L.lead ? uint32_t(i) : kOob;          // reward / done / info: element index of the row's lead lane
-  const __amdgpu_buffer_rsrc_t r_obs = team_rsrc(obs, obs_bytes), r_rew = team_rsrc(reward_out, uint32_t(n_envs) * uint32_t(sizeof(X))),
-                               r_done = team_rsrc(done, uint32_t(n_envs)), r_info = team_rsrc(info, uint32_t(n_envs) * 4u),
-                               r_term = team_rsrc(tl.terminal_obs, tl.terminal_obs ? obs_bytes : 0u);
+  uint32_t voA = L.okA ? rowb + L.offA * 4u : kOob, voB = L.okB ? rowb + L.offB * 4u : kOob, voC = L.okC ? rowb + L.offC * 4u : kOob;
+  asm volatile("" : "+v"(voA), "+v"(voB), "+v"(voC));
+  const __amdgpu_buffer_rsrc_t r_obs = team_rsrc(obs, obs_bytes), r_term = team_rsrc(tl.terminal_obs, tl.terminal_obs ? obs_bytes : 0u);
   AMENV_STAMP(1);          // loads issued
   AMENV_STAMP_DRAIN();
   AMENV_STAMP(2);          // loads landed
@@ -402,10 +469,7 @@ __global__ __launch_bounds__(128) void step_kernel_team(void* __restrict__ blob,
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(float(o.vA)), r_obs, int(voA), 0, 0);
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(float(o.vB)), r_obs, int(voB), 0, 0);
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(float(o.vC)), r_obs, int(voC), 0, 0);
-  if constexpr (sizeof(X) == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(o.reward), r_rew, int(vo1 == kOob ? kOob : vo1 * 4u), 0, 0);
-  else if (active && L.lead) reward_out[i] = o.reward;
-  __builtin_amdgcn_raw_buffer_store_b8(uint8_t(o.ended ? 1 : 0), r_done, int(vo1), 0, 0);
-  __builtin_amdgcn_raw_buffer_store_b32(int(o.bits), r_info, int(vo1 == kOob ? kOob : vo1 * 4u), 0, 0);
+  if (active && L.lead) { reward_out[uint32_t(i)] = o.reward; done[uint32_t(i)] = o.ended ? 1 : 0; info[uint32_t(i)] = o.bits; }
   if (any_end) {           // wave-uniform; rows that did not end store nowhere
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(float(tA)), r_term, int(o.ended ? voA : kOob), 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(float(tB)), r_term, int(o.ended ? voB : kOob), 0, 0);

@@ -32,6 +32,18 @@ std::vector<T> team_const_table(const amenv_config& c, bool packed4) {
         for (int j = 0; j < 3; j++) t[size_t(TC_NTR0 + 3 * k + j) * 16 + l] = cc == j ? -tr : T(0);
       }
       for (int r = 0; r < v.n_rotors && r < 6; r++) { set(TC_ALLOC0 + r, v.alloc[r * 4 + cc]); set(TC_MIX0 + r, v.mix[cc * v.n_rotors + r]); }
+      {   // lane-team mixer: this lane's rotor = 4 b + cc
+        const int rot = 4 * b + cc;
+        const bool has = rot < v.n_rotors && rot < 6;
+        for (int j = 0; j < 4; j++) set(TC_ALC0 + j, has ? v.alloc[rot * 4 + j] : 0.0);
+        set(TC_TMIN, has ? v.t_min[rot] : 0.0); set(TC_TMAX, has ? v.t_max[rot] : 0.0);
+        for (int j = 0; j < 4; j++) { const int rj = 4 * b + j; set(TC_MXQ0 + j, (rj < v.n_rotors && rj < 6) ? v.mix[cc * v.n_rotors + rj] : 0.0); }
+      }
+      set(TC_E01, cc < 2 ? 1.0 : 0.0); set(TC_ZX, cc == 0 ? -1.0 : (cc == 1 ? 1.0 : 0.0));
+      if (cc < 3 && v.n_joints > 0) {
+        for (int j = 0; j < 3; j++) set(TC_I1C0 + j, v.link_inertia[3 * cc + j]);
+        set(TC_LC0, v.link_com[cc]); set(TC_O1, v.joint_origin[3 + cc]);
+      }
       const double sp[4] = {.5, -.5, .5, -.5}, sq[4] = {.5, -.5, -.5, .5}, sr[4] = {.5, .5, -.5, -.5};
       set(TC_SP, sp[cc]); set(TC_SQ, sq[cc]); set(TC_SR, sr[cc]);
       t[size_t(TC_ACT1) * 16 + l] = T(cc == 0 ? float(v.mass) : float(v.moment_scale));
@@ -74,7 +86,6 @@ TeamParamsT<T> make_team_params(const amenv_config& c, const void* consts) {
   P.mtot = T(v.mass); P.inv_mtot = T(1.0 / v.mass); P.g = T(v.g);
   const int ns = c.task.rk4_substeps > 0 ? c.task.rk4_substeps : 1;
   P.h = T(c.task.dt / ns); P.substeps = ns;
-  for (int r = 0; r < 6; r++) { P.tmin[r] = T(v.t_min[r]); P.tmax[r] = T(v.t_max[r]); }
   P.max_steps = c.task.max_episode_steps; P.counter_limit = c.task.counter_limit; P.flags = c.flags;
   P.ee_task = c.task.ee_task == AMENV_EE_TASK_TOOL ? 1 : 0;
   P.K = 1;

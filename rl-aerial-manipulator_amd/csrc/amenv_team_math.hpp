@@ -31,6 +31,7 @@
 // The translational acceleration is off the chain: after round 4 quad s holds stage s's (Q, w, wd) and computes ITS stage's vd, all four at
 // once; the RK4 combination is one weighted row sum per state register (sum_bodies: bit-identical in the four quads).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace amenv_dev {
@@ -39,34 +40,48 @@ template <typename X> struct LaneTraits { using T = X; using M = bool; };   // s
 
 // Per-lane constants: a table built by amenv_create (amenv_team_host.hpp), constant k of lane column 4 * quad + component.
 enum TeamConst {
-  TC_E0 = 0, TC_E1, TC_E2,                             // 1 if component == j
+  // shared with the rigid lane-quad kernel (amenv_quad.hpp): three 16-byte pieces it loads anyway + one of its own
+  TC_E0 = 0, TC_E1, TC_E2, TC_GV,                      // 1 if component == j; gravity (0, 0, -g)
+  TC_SP, TC_SQ, TC_SR, TC_O0,                          // signs of the quaternion kinematics (incl. the 1/2); joint-1 origin (component per lane)
+  TC_ACT1, TC_ACT2, TC_JHALF, TC_JMID,                 // action scaling u = (a * ACT1) * ACT2: (mass, ms, ms, ms), (g, 1, 1, 1) -- fp32, left to right; joint command = fma(action, half, mid)
+  TC_ALLOC0, TC_MIX0 = TC_ALLOC0 + 6,                  // lane-quad kernel only: alloc[r][component], mix[component][r], r = 0..5 (three pieces the team kernel never loads)
+  // lane-team kernels
+  TC_GV1 = TC_MIX0 + 6, TC_GV2,                        // the two rotations of the gravity vector
+  TC_E01, TC_ZX,                                       // (1, 1, 0, 0); (-1, 1, 0, 0): e_z x v = ZX * quad_perm[1,0,2,3](v)
   TC_I0C0, TC_I0C1, TC_I0C2,                           // base body inertia about its CoM: column j, row = component
+  TC_I1C0, TC_I1C1, TC_I1C2,                           // link 1 inertia (link frame), column j
+  TC_LC0, TC_O1,                                       // link 1 CoM in its frame; joint-2 origin in link 1's frame (component per lane)
   TC_NTR0, TC_NTR_END = TC_NTR0 + 9,                   // -tr(I_link k) e_j at TC_NTR0 + 3 k + j
-  TC_ALLOC0 = TC_NTR_END, TC_MIX0 = TC_ALLOC0 + 6,     // alloc[r][component], mix[component][r] (component = wrench entry F, Mx, My, Mz), r = 0..5
-  TC_SP = TC_MIX0 + 6, TC_SQ, TC_SR,                   // signs of the quaternion kinematics (incl. the 1/2)
-  TC_ACT1, TC_ACT2,                                    // action scaling u = (a * ACT1) * ACT2: (mass, ms, ms, ms), (g, 1, 1, 1) -- fp32, left to right
-  TC_JHALF, TC_JMID,                                   // joint command = fma(action, half, mid), joint = component
-  TC_O0,                                               // joint-1 origin (component per lane)
-  TC_GV, TC_GV1, TC_GV2,                               // (0, 0, -g) and its two rotations
+  TC_ALC0 = TC_NTR_END, TC_ALC1, TC_ALC2, TC_ALC3,     // mixer, lane = rotor (lanes 0..5 of the row): alloc[rotor][0..3]
+  TC_TMIN, TC_TMAX,                                    // ... its thrust limits
+  TC_MXQ0, TC_MXQ1, TC_MXQ2, TC_MXQ3,                  // re-mix: mix[component][4 quad + j] (0 where there is no such rotor)
   TC_OBS_A, TC_OBS_B, TC_OBS_C,                        // observation scalings of the three row segments this lane writes
   TC_HSTEP,                                            // RK4 hand-over: stage state of this quad = y + HSTEP * (previous quad's derivative): 0, h/2, h/2, h
   TC_WGT,                                              // RK4 weights of this quad's stage: h/6 * (1, 2, 2, 1)
   TC_PW,                                               // position: h * h/6 * (1, 1, 1, 0)
   kTeamConsts
 };
+constexpr int kTeamFirstPiece = TC_GV1 / 4;            // the team kernels load pieces 0..2 and from here on
+static_assert(TC_ALLOC0 % 4 == 0 && TC_GV1 % 4 == 0, "the lane-quad kernel's mixer constants fill whole 16-byte pieces");
 
 template <typename T>
 struct TeamParamsT {          // wave-uniform (SGPRs)
   T o1[3], o2[3];            // joint-2 / joint-3 origins in their parent frames
   T tool[3];
   T kp, kd, amax, mtot, inv_mtot, g, h;
-  T tmin[6], tmax[6];
   T ee_home[3];
   T lm[3], lcm[3][3], li[3][6];   // link masses, CoMs (link frame), inertias (xx xy xz yy yz zz)
   int32_t substeps, max_steps, counter_limit, ee_task, K;   // K = 1 (the task code reads it)
   uint32_t flags;
   const void* consts;        // per-lane constant table (layout: amenv_team_host.hpp)
 };
+
+// Device block of the step kernel: the per-lane table, then the wave-uniform parameters.  The step kernel reads the parameters from THERE
+// with scalar loads (cached in L2 like any data) instead of from its kernel arguments: a trip to the kernel-argument segment is served from
+// memory on every launch and costs ~600 clocks per batch, which would sit in front of the RK4 for every value it needs.
+constexpr int kTeamTablePieces = (kTeamConsts + 3) / 4;
+template <typename T> constexpr size_t team_table_bytes() { return size_t(kTeamTablePieces) * 4 * 16 * sizeof(T); }
+template <typename T> constexpr size_t team_block_bytes() { return team_table_bytes<T>() + sizeof(TeamParamsT<T>); }
 
 template <typename X> struct TeamStateT { X P, V, Q, W, TH, THD; };   // one register each: position, velocity (component per lane), quaternion (4 lanes), body rates, joints
 
@@ -117,17 +132,54 @@ template <typename X, typename PT>
 AMENV_FN TeamStage<X> team_kin_stage(const PT& P, const X* c, X TH, X THD, X thdd, X Fe2, X Mv) {
   using T = typename LaneTraits<X>::T;
   const X e0 = c[TC_E0], e1 = c[TC_E1], e2 = c[TC_E2];
-  X S = T(0), U = T(0), Aa = T(0), Tn = T(0);
+  X S, U, Aa, Tn;
   TM<X> IO{c[TC_I0C0], c[TC_I0C1], c[TC_I0C2]};          // base body: r = 0, J = I0
   TM<X> G{T(0), T(0), T(0)};
+  X sIO = T(0), sG = T(0);                               // the isotropic parts m |r|^2 and 2 m (u . r): added to the diagonals once, after the links
   TM<X> R;
-  X p, pd = T(0), pdd = T(0), w, al;
-  {   // joint 1 about z at the start of the chain
+  X p, pd, pdd, w, al;
+  {   // joint 1 about z at the start of the chain and link 1 behind it: R = Rz(th), w = thd e_z, al = thdd e_z, the frame origin at rest
     X s, co;
     sincos_t(bc<0>(TH), s, co);
-    p = c[TC_O0];
-    w = bc<0>(THD) * e2; al = bc<0>(thdd) * e2;
+    const X td = bc<0>(THD), tdd = bc<0>(thdd);
+    const X cov = fma_(co, c[TC_E01], e2), sv = s * c[TC_ZX];
+    auto zrot = [&](X v) { return fma_(cov, v, sv * qp<1, 0, 2, 3>(v)); };   // Rz v
+    auto zx = [&](X v) { return c[TC_ZX] * qp<1, 0, 2, 3>(v); };             // e_z x v
     R.c0 = fma_(co, e0, s * e1); R.c1 = fma_(co, e1, -(s * e0)); R.c2 = e2;
+    p = c[TC_O0];
+    {
+      const T m = P.lm[0];
+      const X Rc = zrot(c[TC_LC0]), zRc = zx(Rc);
+      const X r = p + Rc, u = td * zRc;                   // u = w x Rc
+      const X a_ = fma_(tdd, zRc, td * zx(u));            // al x Rc + w x (w x Rc)
+      const X A0 = zrot(c[TC_I1C0]), A1 = zrot(c[TC_I1C1]), A2 = zrot(c[TC_I1C2]);   // Rz I, columns
+      const TM<X> J{fma_(co, A0, -(s * A1)), fma_(s, A0, co * A1), A2};              // (Rz I) Rz^T
+      S = m * r; U = m * u; Aa = m * a_;
+      const X mr = m * r;
+      sIO = m * dot3(r, r);
+      const X r0 = bc<0>(r), r1 = bc<1>(r), r2 = bc<2>(r);
+      IO.c0 = IO.c0 + fma_(-mr, r0, J.c0); IO.c1 = IO.c1 + fma_(-mr, r1, J.c1); IO.c2 = IO.c2 + fma_(-mr, r2, J.c2);
+      const T m2 = m + m;
+      const X mu = m2 * u;
+      sG = m2 * dot3(u, r);
+      G.c0 = fma_(td, zx(fma_(T(2), J.c0, c[TC_NTR0 + 0])), -(mu * r0));      // [w]x (2 J - tr(J) 1) = thd [e_z]x (...)
+      G.c1 = fma_(td, zx(fma_(T(2), J.c1, c[TC_NTR0 + 1])), -(mu * r1));
+      G.c2 = fma_(td, zx(fma_(T(2), J.c2, c[TC_NTR0 + 2])), -(mu * r2));
+      Tn = fma_(m, cross_c(x3(r), a_), fma_(tdd, J.c2, (td * td) * zx(J.c2)));   // m r x a + J al + w x (J w)
+    }
+    {   // across joint 2 (about link 1's x axis = column 0 of R) with the parent at w = thd e_z
+      X s2, co2;
+      sincos_t(bc<1>(TH), s2, co2);
+      const X td1 = bc<1>(THD), tdd1 = bc<1>(thdd);
+      const X Ro = zrot(c[TC_O1]), zRo = zx(Ro);
+      pd = td * zRo;
+      pdd = fma_(tdd, zRo, td * zx(pd));
+      p = p + Ro;
+      const X z = R.c0;
+      al = fma_(td1, td * zx(z), fma_(tdd1, z, tdd * e2));    // al + z thdd + (w x z) thd
+      w = fma_(td1, z, td * e2);
+      rotate_cols<0>(R, s2, co2);
+    }
   }
   auto link = [&](int k) {   // link k behind the joints advanced so far: CoM motion relative to the body frame, inertia in body axes, sums
     const T m = P.lm[k];
@@ -142,17 +194,17 @@ AMENV_FN TeamStage<X> team_kin_stage(const PT& P, const X* c, X TH, X THD, X thd
     const TM<X> J{fma_(RI0, bc<0>(R.c0), fma_(RI1, bc<0>(R.c1), RI2 * bc<0>(R.c2))), fma_(RI0, bc<1>(R.c0), fma_(RI1, bc<1>(R.c1), RI2 * bc<1>(R.c2))),
                   fma_(RI0, bc<2>(R.c0), fma_(RI1, bc<2>(R.c1), RI2 * bc<2>(R.c2)))};
     S = fma_(m, r, S); U = fma_(m, u, U); Aa = fma_(m, a_, Aa);
-    const X mr2 = m * dot3(r, r), mr = m * r;
+    const X mr = m * r;
+    sIO = fma_(m, dot3(r, r), sIO);
     const X r0 = bc<0>(r), r1 = bc<1>(r), r2 = bc<2>(r);
-    IO.c0 = IO.c0 + fma_(-mr, r0, fma_(mr2, e0, J.c0));
-    IO.c1 = IO.c1 + fma_(-mr, r1, fma_(mr2, e1, J.c1));
-    IO.c2 = IO.c2 + fma_(-mr, r2, fma_(mr2, e2, J.c2));
+    IO.c0 = IO.c0 + fma_(-mr, r0, J.c0); IO.c1 = IO.c1 + fma_(-mr, r1, J.c1); IO.c2 = IO.c2 + fma_(-mr, r2, J.c2);
     // G += 2 m ((u . r) 1 - u r^T) + [w]x (2 J - tr(J) 1): the point mass's 2 m r x (W x u) and the link's J (W x w) + W x (J w) + w x (J W)
     const T m2 = m + m;
-    const X d = m2 * dot3(u, r), mu = m2 * u;
-    G.c0 = G.c0 + (fma_(-mu, r0, d * e0) + cross_c(xw, fma_(T(2), J.c0, c[TC_NTR0 + 3 * k + 0])));
-    G.c1 = G.c1 + (fma_(-mu, r1, d * e1) + cross_c(xw, fma_(T(2), J.c1, c[TC_NTR0 + 3 * k + 1])));
-    G.c2 = G.c2 + (fma_(-mu, r2, d * e2) + cross_c(xw, fma_(T(2), J.c2, c[TC_NTR0 + 3 * k + 2])));
+    const X mu = m2 * u;
+    sG = fma_(m2, dot3(u, r), sG);
+    G.c0 = G.c0 + (cross_c(xw, fma_(T(2), J.c0, c[TC_NTR0 + 3 * k + 0])) - mu * r0);
+    G.c1 = G.c1 + (cross_c(xw, fma_(T(2), J.c1, c[TC_NTR0 + 3 * k + 1])) - mu * r1);
+    G.c2 = G.c2 + (cross_c(xw, fma_(T(2), J.c2, c[TC_NTR0 + 3 * k + 2])) - mu * r2);
     const X Jw = matvec(J, w);
     Tn = Tn + (fma_(m, cross_c(x3(r), a_), matvec(J, al)) + cross_c(xw, Jw));
   };
@@ -171,8 +223,6 @@ AMENV_FN TeamStage<X> team_kin_stage(const PT& P, const X* c, X TH, X THD, X thd
     w = fma_(td, z, w);
     rotate_cols<0>(R, s, co);
   };
-  link(0);
-  advance_x(bc<1>(TH), bc<1>(THD), bc<1>(thdd), P.o1);
   link(1);
   advance_x(bc<2>(TH), bc<2>(THD), bc<2>(thdd), P.o2);
   link(2);
@@ -181,15 +231,16 @@ AMENV_FN TeamStage<X> team_kin_stage(const PT& P, const X* c, X TH, X THD, X thd
   const T im = P.inv_mtot;
   const X imS2 = im * dot3(S, S), imS = im * S;
   const X S0 = bc<0>(S), S1 = bc<1>(S), S2 = bc<2>(S);
-  k.Ic = TM<X>{fma_(imS, S0, fma_(-imS2, e0, IO.c0)), fma_(imS, S1, fma_(-imS2, e1, IO.c1)), fma_(imS, S2, fma_(-imS2, e2, IO.c2))};
+  const X dI = sIO - imS2;
+  k.Ic = TM<X>{fma_(imS, S0, fma_(dI, e0, IO.c0)), fma_(imS, S1, fma_(dI, e1, IO.c1)), fma_(imS, S2, fma_(dI, e2, IO.c2))};
   const X3<X> x0 = x3(k.Ic.c0), x1 = x3(k.Ic.c1), x2 = x3(k.Ic.c2);
   const TM<X> A{cross(x1, x2), cross(x2, x0), cross(x0, x1)};
   const X idet = rcp_(dot3(x0.v, A.c0));
   k.C = TM<X>{idet * A.c0, idet * A.c1, idet * A.c2};
   // L = -G + (2 / mtot) ((S . U) 1 - U S^T)
   const T im2 = im + im;
-  const X imU2 = im2 * U, imSU2 = im2 * dot3(S, U);
-  k.L = TM<X>{fma_(-imU2, S0, fma_(imSU2, e0, -G.c0)), fma_(-imU2, S1, fma_(imSU2, e1, -G.c1)), fma_(-imU2, S2, fma_(imSU2, e2, -G.c2))};
+  const X imU2 = im2 * U, dL = fma_(im2, dot3(S, U), -sG);
+  k.L = TM<X>{fma_(-imU2, S0, fma_(dL, e0, -G.c0)), fma_(-imU2, S1, fma_(dL, e1, -G.c1)), fma_(-imU2, S2, fma_(dL, e2, -G.c2))};
   k.S = x3(S); k.U = x3(U); k.Aa = Aa;
   k.c0 = fma_(im, cross_c(k.S, Aa - Fe2), Mv - Tn);
   return k;
@@ -258,17 +309,15 @@ template <typename X> struct TeamStageDeriv { X dV, dQ, dW, Qs, Ws; };
 // One control step of the dynamics of one env row, state in registers: mixer -> per-rotor clamp -> re-mix (quadcopter.py:109-112), joint
 // commands, RK4 (sub-steps), renormalisation.  act: wrench action a0..a3 (one per lane), actj: joint actions (joint per lane).
 // q0..q2: "this lane sits in quad 0 / 1 / 2" (quad s takes RK4 stage s + 1).  Returns the tool offset of the new state.
-template <int NROT, typename X, typename PT, typename M>
+template <typename X, typename PT, typename M>
 AMENV_FN X team_dynamics(const PT& P, const X* c, M q0, M q1, M q2, TeamStateT<X>& y, X act, X actj, TeamStageDeriv<X>* probe = nullptr) {
   using T = typename LaneTraits<X>::T;
+  // mixer: lane 4 q + j of the row takes rotor 4 q + j (rotors 0..5 in quads 0 and 1): thrust = alloc[rotor] . u, clamp, then wrench
+  // entry c = sum over rotors of mix[c][rotor] * thrust: per quad over its own four lanes, then over the quads of the row
   const X uu = scale_action_f32(act, c[TC_ACT1], c[TC_ACT2]);
-  X wr = T(0);
-#pragma unroll
-  for (int r = 0; r < NROT; r++) {
-    X t = sum4(c[TC_ALLOC0 + r] * uu);
-    t = clamp_(t, P.tmin[r], P.tmax[r]);
-    wr = fma_(c[TC_MIX0 + r], t, wr);
-  }
+  X t = fma_(c[TC_ALC0], bc<0>(uu), fma_(c[TC_ALC1], bc<1>(uu), fma_(c[TC_ALC2], bc<2>(uu), c[TC_ALC3] * bc<3>(uu))));
+  t = clamp_(t, c[TC_TMIN], c[TC_TMAX]);
+  const X wr = sum_bodies(fma_(c[TC_MXQ0], bc<0>(t), fma_(c[TC_MXQ1], bc<1>(t), fma_(c[TC_MXQ2], bc<2>(t), c[TC_MXQ3] * bc<3>(t)))));
   const X Fe2 = bc<0>(wr) * c[TC_E2], Mv = qp<1, 2, 3, 3>(wr);
   const X cmd = joint_cmd_f32(actj, c[TC_JHALF], c[TC_JMID]);
   const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);

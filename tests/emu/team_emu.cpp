@@ -88,7 +88,7 @@ extern "C" int team_emu_step(const amenv_config* cfg, double* s19, const float* 
       act.x[l] = a[cc]; actj.x[l] = a[4 + (cc < 3 ? cc : 2)];
     }
     TeamStageDeriv<HV> pr;
-    const HV EO = team_dynamics<6>(P, c, q0, q1, q2, y, act, actj, &pr);
+    const HV EO = team_dynamics(P, c, q0, q1, q2, y, act, actj, &pr);
     if (quad_check) {
       double d = 0.0;
       for (int l = 4; l < 16; l++) {
