@@ -379,49 +379,58 @@ def extras(args, amd, torch, env, ring, n, device):
         st = e2.stats()
         prot[tag] = {"env_steps_per_s": S * n / (ms * 1e-3), "us_per_step": ms * 1e3 / S, "episodes_per_1000_env_steps": 1000.0 * st["episodes"] / (5.0 * S * n)}
         e2.close()
-    # C: policy in the loop (the reference's architecture, random-init weights of this vehicle's obs / action dims: no checkpoint exists for the arm)
-    pol = amd.ActorCritic(env.obs_dim, env.act_dim).to(device)
-    pol.flatten_()   # parameters as views of one flat buffer: what the fused forward kernel reads
-    e3 = amd.GpuWaypointEnv(n, device=device.index, vehicle=args.vehicle, seed=0, dtype=args.dtype, kernel=args.kernel)
-    obs = e3.reset()
-    lo, hi = pol.action_low, pol.action_high
+    # C: policy in the loop (the reference's architecture 128-64-64 tanh, random-init weights of the vehicle's obs / action dims), twice: one launch per
+    # operation (fused fp32 policy forward, clip, step) and ONE launch per 64 steps (amenv_rollout_policy: bf16 actor / critic on the matrix cores,
+    # sampling, clip, env step; state, constants and weights in registers -- the opt-in rollout mode of amd.PPO(fused_rollout=True)).  For the
+    # benchmark's vehicle and, as `reference_vehicle`, for the quadrotor the reference trains (v2/rl_train.py:24,38-56).
+    def closed_loop_pair(vehicle):
+        out = {}
+        e3 = amd.GpuWaypointEnv(n, device=device.index, vehicle=vehicle, seed=0, dtype=args.dtype, kernel=args.kernel if vehicle == args.vehicle else "auto")
+        pol = amd.ActorCritic(e3.obs_dim, e3.act_dim).to(device)
+        pol.flatten_()   # parameters as views of one flat buffer: what the fused forward kernel reads
+        obs = e3.reset()
+        lo, hi = pol.action_low, pol.action_high
 
-    def closed_loop(k):
-        o = e3.obs
+        def closed_loop(k):
+            o = e3.obs
+            with torch.no_grad():
+                for _ in range(k):
+                    a = torch.max(torch.min(pol.actor(o), hi), lo)
+                    o = e3.step(a)[0]
+
+        closed_loop(8)
+        ms = timed(lambda: closed_loop(S // 8), 5)
         with torch.no_grad():
-            for _ in range(k):
-                a = torch.max(torch.min(pol.actor(o), hi), lo)
-                o = e3.step(a)[0]
+            fused_fwd = bool(pol.fused_ok(obs))
+        out["C_policy_closed_loop"] = {"env_steps_per_s": (S // 8) * n / (ms * 1e-3), "us_per_step": ms * 1e3 / (S // 8), "fused_policy_kernel": fused_fwd,
+                                       "weights": "random init (reference architecture 128-64-64 tanh)", "step_kernel": e3.kernel_name}
+        e3.close()
+        if args.dtype == "f32":
+            e4 = amd.GpuWaypointEnv(n, device=device.index, vehicle=vehicle, seed=0, kernel=args.kernel if vehicle == args.vehicle else "auto")
+            e4.reset()
+            Tf = GRAPH_CHUNK
+            f = dict(dtype=torch.float32, device=device)
+            bo, ba = torch.zeros(Tf + 1, n, e4.obs_dim, **f), torch.zeros(Tf, n, e4.act_dim, **f)
+            bl, bv, br = torch.zeros(Tf, n, **f), torch.zeros(Tf, n, **f), torch.zeros(Tf, n, **f)
+            bd = torch.zeros(Tf, n, dtype=torch.uint8, device=device)
+            draw = [0]
 
-    closed_loop(8)
-    ms = timed(lambda: closed_loop(S // 8), 5)
-    with torch.no_grad():
-        fused = bool(pol.fused_ok(obs))
-    prot["C_policy_closed_loop"] = {"env_steps_per_s": (S // 8) * n / (ms * 1e-3), "us_per_step": ms * 1e3 / (S // 8),
-                                    "fused_policy_kernel": fused, "weights": "random init (reference architecture 128-64-64 tanh)"}
-    e3.close()
-    if args.vehicle == "hexa_arm" and args.dtype == "f32":
-        # the same closed loop as ONE launch per 64 steps: amenv_rollout_policy (bf16 actor / critic on the matrix cores, sampling, clip,
-        # team env step; state, constants and weights in registers) -- the opt-in rollout mode of amd.PPO(fused_rollout=True)
-        e4 = amd.GpuWaypointEnv(n, device=device.index, vehicle=args.vehicle, seed=0, kernel=args.kernel)
-        e4.reset()
-        Tf = GRAPH_CHUNK
-        f = dict(dtype=torch.float32, device=device)
-        bo, ba = torch.zeros(Tf + 1, n, e4.obs_dim, **f), torch.zeros(Tf, n, e4.act_dim, **f)
-        bl, bv, br = torch.zeros(Tf, n, **f), torch.zeros(Tf, n, **f), torch.zeros(Tf, n, **f)
-        bd = torch.zeros(Tf, n, dtype=torch.uint8, device=device)
-        draw = [0]
+            def fused():
+                for _ in range(S // Tf):
+                    e4.rollout_policy(pol.flat_param, Tf, 0, draw[0], bo, ba, bl, bv, br, bd)
+                    draw[0] += Tf
 
-        def fused():
-            for _ in range(S // Tf):
-                e4.rollout_policy(pol.flat_param, Tf, 0, draw[0], bo, ba, bl, bv, br, bd)
-                draw[0] += Tf
+            fused()
+            ms = timed(fused, 5)
+            out["C_policy_closed_loop_one_launch"] = {"env_steps_per_s": S * n / (ms * 1e-3), "us_per_step": ms * 1e3 / S, "steps_per_launch": Tf,
+                                                      "policy_arithmetic": "bf16 MFMA, fp32 accumulate",
+                                                      "what": "amenv_rollout_policy: value + sampled action + log-prob + env step per step, rollout-buffer rows written"}
+            e4.close()
+        return out
 
-        fused()
-        ms = timed(fused, 5)
-        prot["C_policy_closed_loop_one_launch"] = {"env_steps_per_s": S * n / (ms * 1e-3), "us_per_step": ms * 1e3 / S, "steps_per_launch": Tf,
-                                                   "policy_arithmetic": "bf16 MFMA, fp32 accumulate", "what": "amenv_rollout_policy: value + sampled action + log-prob + env step per step, rollout-buffer rows written"}
-        e4.close()
+    prot.update(closed_loop_pair(args.vehicle))
+    if args.vehicle != "quad":
+        prot["reference_vehicle"] = {"vehicle": "quad (v2/simul_files/model/params.py: the vehicle the reference trains)", "envs": n, **closed_loop_pair("quad")}
     ex["survey_8d"] = {"steps": S, "warmup": GRAPH_CHUNK, "repeats": 5, "statistic": "median", **prot}
     return ex
 

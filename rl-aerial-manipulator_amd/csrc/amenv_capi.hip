@@ -19,6 +19,7 @@
 #include "amenv_team_host.hpp"
 #include "amenv_quad.hpp"
 #include "amenv_team_policy.hpp"
+#include "amenv_quad_policy.hpp"
 #include "amenv_lane_policy.hpp"
 #include "amenv_obsnorm.hpp"
 #include "amenv_policy.hpp"
@@ -44,6 +45,7 @@ struct amenv {
   bool pwave = false;              // rigid vehicles at small batches: second wave per tile computes the reset RNG words (step_kernel_pw)
   bool team = false;               // lane-team kernel (16 lanes per env): fp32 z,x,x-arm vehicle in the latency regime (amenv_team.hpp)
   void* team_consts = nullptr;     // per-lane constants of the team kernels (amenv_team_host.hpp): float4 pieces, or plain doubles for the fp64 build
+  bool quad_ok = false;            // fp32 rigid vehicle with 4 or 6 rotors, single-waypoint v2 task: lane-quad kernels (step opt-in, closed-loop rollout)
   bool team_ok = false;            // the configuration has a team kernel (fp32, 6 rotors, z,x,x arm): constants are allocated
   uint32_t* pol_pack = nullptr;    // amenv_rollout_policy: policy parameters as MFMA fragments (re-packed on every call)
   uint64_t steps = 0;
@@ -614,6 +616,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // helper-wave kernel where the launch is latency-bound (2.85 vs 2.86 us at 1024 envs, 2.98 vs 3.00 at 4096) and loses above (3.3 vs 3.2 us at
   // 8192, 5.3 vs 4.3 at 32768: four times the wavefronts): at these sizes the rigid step sits on the dependent-launch floor (1.7 us) plus one
   // load -> compute -> store round trip of memory latency, and an instruction stream half as long changes nothing.
+  e->quad_ok = quad_ok;
   e->quadk = quad_ok && want == AMENV_KERNEL_TEAM;
   if (e->quadk) e->pwave = false;
   if (want == AMENV_KERNEL_TEAM && !e->team && !e->quadk) {
@@ -636,10 +639,11 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
                 "and rk4_substeps = 1");
   }
   if (e->team || e->armk) e->arm2w = false;
-  if (e->quadk) {
+  if (e->quad_ok) {    // the lane-quad kernels' constants (step kernel: opt-in; closed-loop rollout: amenv_rollout_policy) + the packed policy
     const std::vector<float> tc = team_table_f32(*cfg);
     if ((s = hipMalloc((void**)&e->team_consts, tc.size() * sizeof(float))) != hipSuccess ||
-        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
+        (s = hipMemcpy(e->team_consts, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+        (s = hipMalloc((void**)&e->pol_pack, size_t(kPolPackWords) * sizeof(uint32_t))) != hipSuccess) {
       std::string msg = std::string("amenv_create: quad constants: ") + hipGetErrorString(s);
       amenv_destroy(e);
       return fail(nullptr, AMENV_ERR_ALLOC, msg);
@@ -791,20 +795,31 @@ int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, v
 int amenv_rollout_policy(amenv* e, int32_t n_steps, const float* flat_params, uint64_t seed, uint32_t draw0, float* obs, float* actions, float* logp,
                          float* values, float* rewards, uint8_t* dones, uint32_t* info_bits, float* terminal_obs, void* stream) {
   if (!e) return AMENV_ERR_INVALID;
-  if (!e->team_ok) return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: built for the fp32 6-rotor vehicle with the z,x,x arm (v2 task, 1 waypoint)");
+  if (!e->team_ok && !e->quad_ok)
+    return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: built for fp32 vehicles on the single-waypoint v2 task: rigid with 4 or 6 rotors (default workgroup size), or the "
+                "6-rotor vehicle with the z,x,x arm");
   if (n_steps <= 0 || !flat_params || !obs || !actions || !logp || !values || !rewards || !dones)
     return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: n_steps must be > 0 and flat_params / obs / actions / logp / values / rewards / dones non-NULL");
   DeviceGuard g(e->device);
   hipStream_t s = (hipStream_t)stream;
   const int obs_dim = e->obs_dim, act_dim = e->act_dim;   // 29, 7
   // parameters -> bf16 MFMA fragments + per-lane action constants (they change every PPO iteration): a tiny kernel in front, no host sync
-  const int pack_threads = 4 * (kPolFrags + kPolBias) * 64 + 64;
+  const int pack_threads = 4 * (kPolFrags + kPolBias) * 64 + 64 + 4 * 4 * 64;
   hipLaunchKernelGGL(policy_pack_kernel, dim3((pack_threads + 255) / 256), dim3(256), 0, s, flat_params, obs_dim, act_dim, e->pol_pack);
   PolicyIO io;
   io.pack = reinterpret_cast<const uint4*>(e->pol_pack);
   io.seed_lo = uint32_t(seed); io.seed_hi = uint32_t(seed >> 32); io.draw0 = draw0;
   io.obs = obs; io.actions = actions; io.logp = logp; io.values = values; io.rewards = rewards; io.dones = dones; io.info = info_bits;
   io.terminal_obs = terminal_obs;
+  if (e->quad_ok) {   // rigid vehicle: 16 envs per workgroup, the lane-quad step inside (amenv_quad_policy.hpp)
+    const QuadParams QP = make_quad(*e);
+    const dim3 gq(e->n_tiles * 4), bq(256);
+    if (e->cfg.vehicle.n_rotors == 4) hipLaunchKernelGGL((rollout_policy_kernel_quad<4>), gq, bq, 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io, e->stats, make_cold(*e), QP);
+    else hipLaunchKernelGGL((rollout_policy_kernel_quad<6>), gq, bq, 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io, e->stats, make_cold(*e), QP);
+    AMENV_HIP(e, hipGetLastError());
+    e->steps += uint64_t(e->cfg.num_envs) * uint64_t(n_steps);
+    return AMENV_OK;
+  }
   // The env part follows the step kernel's choice: 16 lanes per env where amenv_step runs the lane-team kernel (small batches), else one
   // lane per env (amenv_lane_policy.hpp; 64 envs per workgroup up to 16384 envs, 128 above: one workgroup per CU either way).
   if (!e->team) {
@@ -824,8 +839,7 @@ int amenv_rollout_policy(amenv* e, int32_t n_steps, const float* flat_params, ui
   const TeamParams TP = make_team<float>(*e);
   // one 16-env workgroup per CU up to 4096 envs (5.15 vs 5.22 us per step there); above that the variant compiled for two wavefronts per SIMD pays
   // (measured on MI355X at 8192 envs: 7.9 vs 10.1 us per step)
-  const char* occ_env = std::getenv("AMENV_POLICY_OCC");   // bench / A-B only (tools/): 1 or 2
-  const int occ = occ_env ? std::atoi(occ_env) : (e->cfg.num_envs <= 4096 ? 1 : 2);
+  const int occ = e->cfg.num_envs <= 4096 ? 1 : 2;
   if (occ == 1) hipLaunchKernelGGL((rollout_policy_kernel_team<6, 1>), dim3(e->n_tiles * 4), dim3(256), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io,
                                    e->stats, make_cold(*e), TP);
   else hipLaunchKernelGGL((rollout_policy_kernel_team<6, 2>), dim3(e->n_tiles * 4), dim3(256), 0, s, e->blob, e->tile_bytes, e->cfg.num_envs, (int)n_steps, io, e->stats,

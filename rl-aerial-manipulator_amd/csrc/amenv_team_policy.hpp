@@ -23,7 +23,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPolFrags = 18, kPolBias = 5;                  // per wavefront: weight fragments (uint4 per lane), bias quadruples (float4 per lane)
-constexpr int kPolPackWords = (4 * (kPolFrags + kPolBias) + 1) * 64 * 4;   // dwords of the packed policy: 4 wavefronts + one block of action constants
+constexpr int kPolLoBase = (4 * (kPolFrags + kPolBias) + 1) * 64;          // uint4 index of the first-layer residual fragments (rigid-vehicle rollout)
+constexpr int kPolPackWords = (kPolLoBase + 4 * 4 * 64) * 4;                // dwords of the packed policy: 4 wavefronts + one block of action constants + W1 residuals
 constexpr int kXS = 40, kH1S = 136, kH2S = 72;               // LDS row strides (bf16 elements): 32 / 128 / 64 + 8 of padding
 
 // Flat parameter buffer (SB3 state-dict order, ppo.py ActorCritic.flatten_):
@@ -43,12 +44,31 @@ __device__ __forceinline__ uint32_t bf16_bits(float x) { return uint32_t(__built
 __global__ void policy_pack_kernel(const float* __restrict__ Pm, int D, int A, uint32_t* __restrict__ out) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_wave = (kPolFrags + kPolBias) * 64;
-  if (tid >= 4 * per_wave + 64) return;
+  if (tid >= 4 * per_wave + 64 + 4 * 4 * 64) return;
+  if (tid >= 4 * per_wave + 64) {   // second bf16 part of the first layer's weights, W1 - bf16(W1) (and of its bias column): fragment (wavefront w, tile j) at kPolLoBase + (4 w + j) * 64
+    const int r = tid - (4 * per_wave + 64), w = r / 256, item = (r % 256) / 64, l = r & 63, row = l & 15, kq = l >> 4;
+    const PolLayout Lo(D, A);
+    const int T = 4 * w + item, net = T >> 3, neuron = 16 * (T & 7) + row;
+    const float* W1 = Pm + (net == 0 ? Lo.o_pi : Lo.o_vf); const float* b1 = W1 + 128 * D;
+    uint32_t o[4];
+    for (int q = 0; q < 4; q++) {
+      uint32_t two[2];
+      for (int h = 0; h < 2; h++) {
+        const int k = 8 * kq + 2 * q + h;
+        const float v = k < D ? W1[neuron * D + k] : (k == D ? b1[neuron] : 0.0f);
+        two[h] = bf16_bits(v - float((__bf16)v));
+      }
+      o[q] = two[0] | (two[1] << 16);
+    }
+    uint32_t* dst = out + (size_t(kPolLoBase) + size_t(4 * w + item) * 64 + l) * 4;
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+    return;
+  }
   if (tid >= 4 * per_wave) {   // per-lane action constants: {std, log_std} of the wrench entry of lane c and of joint min(c, 2)
     const int l = tid - 4 * per_wave, cc = l & 3, cj = cc < 3 ? cc : 2;
     uint32_t* dst = out + size_t(4 * per_wave + l) * 4;
     dst[0] = __float_as_uint(expf(Pm[cc])); dst[1] = __float_as_uint(Pm[cc]);
-    dst[2] = __float_as_uint(expf(Pm[4 + cj])); dst[3] = __float_as_uint(Pm[4 + cj]);
+    dst[2] = A > 4 ? __float_as_uint(expf(Pm[4 + cj])) : 0u; dst[3] = A > 4 ? __float_as_uint(Pm[4 + cj]) : 0u;   // (a rigid vehicle has no joint actions)
     return;
   }
   const int w = tid / per_wave, item = (tid % per_wave) / 64, l = tid & 63;

@@ -514,7 +514,7 @@ class PPO:
 
     def __init__(self, env, policy=None, learning_rate=2e-4, n_steps=2048, batch_size=128, n_epochs=12, gamma=0.995,
                  gae_lambda=0.9, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, max_grad_norm=0.5, normalize_advantage=True,
-                 net_arch=(128, 64, 64), seed=0, obs_normalizer=None, bootstrap_truncated=True, dist=None, use_graph=None, fused_rollout=False, fused_mlp=None):
+                 net_arch=(128, 64, 64), seed=0, obs_normalizer=None, bootstrap_truncated=True, dist=None, use_graph=None, fused_rollout=False, fused_mlp=None, fused_rollout_fp32_stats=True):
         if env.state_dtype != torch.float32:
             raise L.AmenvError("PPO needs the fp32 environment")
         self.env, self.dist = env, dist
@@ -549,6 +549,7 @@ class PPO:
         self._started = False
         # opt-in: the whole rollout (policy MLPs on the bf16 matrix cores, sampling, clip, env step) in ONE launch -- amenv_rollout_policy
         self.fused_rollout = bool(fused_rollout)
+        self.fused_rollout_fp32_stats = bool(fused_rollout_fp32_stats)   # fused rollout: store the fp32 policy's log-probs / values (SB3's buffer semantics)
         if self.fused_rollout and obs_normalizer is not None:
             raise L.AmenvError("fused_rollout does not go through an observation normaliser")
         self._term_obs = self._info = None
@@ -617,6 +618,16 @@ class PPO:
         env.rollout_policy(pol.flat_param, T, self.seed, self._draw, b.obs, b.actions, b.logp, b.values, b.rewards, b.dones, self._info,
                            self._term_obs if self.bootstrap_truncated else None)
         self._draw += T
+        if self.fused_rollout_fp32_stats:
+            # SB3's buffer holds log pi(a|s) and V(s) of the policy the update differentiates: re-evaluate the T*N rows with the fp32 policy (the
+            # fused forward kernel: one launch) so that the first epoch's ratio is exactly 1 and the value targets are the fp32 critic's; the
+            # samples themselves stay those of the bf16 behaviour policy (its means are ~1e-2 of their scale away)
+            flat_obs = b.obs[:T].reshape(T * env.num_envs, env.obs_dim)
+            mean, value = pol.actor_critic(flat_obs)
+            ls = pol.log_std.data
+            zz = (b.actions.reshape(T * env.num_envs, -1) - mean) * torch.exp(-ls)
+            b.logp.copy_((-0.5 * zz * zz - ls - 0.918938533204672742).sum(1).reshape(T, env.num_envs))
+            b.values.copy_(value.reshape(T, env.num_envs))
         if self.bootstrap_truncated:
             trunc = ((self._info & (L.INFO_TERMINATED | L.INFO_TRUNCATED)) == L.INFO_TRUNCATED) & (b.dones != 0)
             idx = trunc.reshape(-1).nonzero().reshape(-1)

@@ -639,3 +639,145 @@ def test_fused_update_with_rccl_exchange_between_reduce_and_adam():
         assert torch.equal(res[0], res[1]) and float(t.sum()) == 4.0
     finally:
         dist.destroy_process_group()
+
+
+# ---- closed-loop rollout in one launch for the rigid vehicles (amenv_quad_policy.hpp) ----------------------------
+def _quad_rollout_buffers(T, n, dev):
+    return dict(obs=torch.zeros(T + 1, n, 20, device=dev), actions=torch.zeros(T, n, 4, device=dev), logp=torch.zeros(T, n, device=dev),
+                values=torch.zeros(T, n, device=dev), rewards=torch.zeros(T, n, device=dev), dones=torch.zeros(T, n, dtype=torch.uint8, device=dev))
+
+
+@pytest.mark.parametrize("vehicle,n", [("quad", 300), ("quad", 4096), ("hexa", 1000)])
+def test_rigid_closed_loop_policy_rollout_kernel(vehicle, n):
+    """amenv_rollout_policy on the reference's vehicle: the env part EXACTLY (replaying the recorded clipped actions through amenv_step on a
+    lane-quad env reproduces every observation / reward / flag bit for bit), the policy part against the fp32 modules (bf16 tolerance), the
+    noise statistically, determinism."""
+    T = 96
+    torch.manual_seed(7)
+    pol = ActorCritic(20, 4).cuda().flatten_()
+    with torch.no_grad():
+        pol.log_std.data.fill_(-1.2)
+        pol.action_net.weight.mul_(30.0)
+    env = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=4, max_episode_steps=60)                 # AUTO step kernel: the rollout brings its own env code
+    ref = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=4, max_episode_steps=60, kernel="team")  # the lane-quad step kernel: the same arithmetic
+    assert "step_kernel_quad" in ref.kernel_name
+    o0 = env.reset().clone(); ref.reset()
+    dev = env.device
+    b = _quad_rollout_buffers(T, n, dev)
+    info = torch.zeros(T, n, dtype=torch.int32, device=dev); tobs = torch.full((T, n, 20), float("nan"), device=dev)
+    env.rollout_policy(pol.flat_param, T, seed=77, draw0=5, info_bits=info, terminal_obs=tobs, **b)
+    torch.cuda.synchronize()
+    assert torch.equal(b["obs"][0], o0)
+    lo, hi = pol.action_low, pol.action_high
+    for t in range(T):
+        o, r, d, i = ref.step(torch.max(torch.min(b["actions"][t], hi), lo))
+        assert torch.equal(o, b["obs"][t + 1]) and torch.equal(r, b["rewards"][t]) and torch.equal(d, b["dones"][t]) and torch.equal(i, info[t]), t
+        dn = d.bool()
+        if bool(dn.any()):
+            assert torch.equal(ref.terminal_obs[dn], tobs[t][dn])
+    f1, i1 = env.get_state(); f2, i2 = ref.get_state()
+    assert torch.equal(f1, f2) and torch.equal(i1, i2) and env.stats()["episodes"] == ref.stats()["episodes"] == int(b["dones"].sum()) > n // 2
+    assert bool(torch.isnan(tobs[~b["dones"].bool()]).all())
+    with torch.no_grad():
+        flat = b["obs"][:T].reshape(T * n, 20)
+        mean32 = pol.action_net(pol.mlp_extractor.policy_net(flat)); v32 = pol.value_net(pol.mlp_extractor.value_net(flat)).reshape(-1)
+    std = torch.exp(pol.log_std.detach())
+    assert float((b["values"].reshape(-1) - v32).abs().max()) < 3e-2 * max(1.0, float(v32.abs().max()))
+    z = (b["actions"].reshape(T * n, 4) - mean32) / std
+    assert abs(float(z.mean())) < 0.03 and abs(float(z.var()) - 1.0) < 0.04 and float(z.abs().max()) < 6.5
+    assert float((torch.corrcoef(z[:50000].T) - torch.eye(4, device=dev)).abs().max()) < 0.04
+    lp32 = (-0.5 * z * z - pol.log_std.detach() - 0.9189385332).sum(1)
+    assert float((b["logp"].reshape(-1) - lp32).abs().max()) < 0.5 and float((b["logp"].reshape(-1) - lp32).abs().mean()) < 0.05
+    env2 = amd.GpuWaypointEnv(n, vehicle=vehicle, seed=4, max_episode_steps=60); env2.reset()
+    b2 = _quad_rollout_buffers(T, n, dev)
+    env2.rollout_policy(pol.flat_param, T, seed=77, draw0=5, **b2)
+    assert torch.equal(b2["actions"], b["actions"]) and torch.equal(b2["obs"], b["obs"])
+    env.close(); ref.close(); env2.close()
+
+
+def test_reference_checkpoint_inside_the_fused_rollout():
+    """The reference's best checkpoint (v2/README.md:55; runsim_scaledObs.py:15) INSIDE the one-launch rollout: (1) teacher-forced on every state
+    of the four recorded policy episodes, the kernel's deterministic action (log_std -> -20: sample == bf16 mean) is within 3e-2 of the action
+    the reference recorded there; (2) sampled closed loop with the checkpoint's own log_std it still succeeds in > 95 % of its episodes, with the
+    return / length of the step-by-step fp32 path."""
+    from oracle import oracle as O
+    from tests.golden_util import load, fill_blob
+    pol = fixture_policy("cuda").flatten_()
+    ls = pol.log_std.data.clone()
+    worst = 0.0; rows = 0; errs = []
+    for name in ("policy_ep0", "policy_ep1", "policy_ep2", "policy_ep3"):
+        d = load(name)
+        T = d["actions"].shape[0]
+        env = amd.GpuWaypointEnv(T, seed=1)
+        env.reset()
+        f, i = env.get_state()
+        f = f.cpu().numpy().astype(np.float64); i = i.cpu().numpy()
+        fill_blob(f, i, d)
+        env.set_state(f.astype(np.float32), i)
+        b = _quad_rollout_buffers(1, T, env.device)
+        with torch.no_grad():
+            pol.log_std.data.fill_(-20.0)
+        env.rollout_policy(pol.flat_param, 1, seed=0, draw0=0, **b)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(b["obs"][0].cpu().numpy()[1:], d["obs"][:-1], rtol=0, atol=2e-6)     # the kernel saw the recorded observations
+        err = (torch.max(torch.min(b["actions"][0], pol.action_high), pol.action_low).cpu() - torch.from_numpy(d["actions"])).abs()
+        worst = max(worst, float(err.max())); rows += T
+        errs.append(err.reshape(-1))
+        env.close()
+    errs = torch.cat(errs)
+    print(f"bf16 policy inside the rollout vs the recorded fp32 actions: max {worst:.4f}, mean {float(errs.mean()):.5f}, 99.9 % {float(errs.quantile(0.999)):.4f}")
+    assert rows > 2000 and worst < 3e-2, worst
+    # (2) closed loop, deterministic as the reference flies it (runsim_scaledObs.py:24 predict(deterministic=True)): the bf16 policy inside the launch
+    n, T = 2048, 100
+    env = amd.GpuWaypointEnv(n, seed=3)
+    env.reset(); env.stats(reset=True)
+    b = _quad_rollout_buffers(T, n, env.device)
+    for k in range(17):
+        env.rollout_policy(pol.flat_param, T, seed=9, draw0=k * T, **b)
+    s = env.stats()
+    assert s["episodes"] > 3000 and s["success"] / s["episodes"] > 0.95, s
+    assert 12000 < s["return_sum"] / s["episodes"] < 26000 and 500 < s["length_sum"] / s["episodes"] < 900
+    env.close()
+    # (3) sampled with the checkpoint's own log_std (what a PPO rollout does): exploration noise costs successes -- as on the step-by-step fp32 path
+    with torch.no_grad():
+        pol.log_std.data.copy_(ls)
+    rates = []
+    for fused in (True, False):
+        env = amd.GpuWaypointEnv(n, seed=3)
+        obs = env.reset(); env.stats(reset=True)
+        if fused:
+            for k in range(17):
+                env.rollout_policy(pol.flat_param, T, seed=9, draw0=k * T, **b)
+        else:
+            act = torch.zeros(n, 4, device=env.device); clipped = torch.zeros_like(act); lp = torch.zeros(n, device=env.device)
+            for k in range(1700):
+                mean, _ = pol.actor_critic(obs)
+                gaussian_act(mean, pol.log_std.data, pol.action_low, pol.action_high, act, clipped, lp, 9, k, 0)
+                obs = env.step(clipped)[0]
+        st = env.stats()
+        rates.append(st["success"] / st["episodes"])
+        env.close()
+    assert abs(rates[0] - rates[1]) < 0.03 and min(rates) > 0.8, rates
+
+
+def test_ppo_fused_rollout_on_the_reference_vehicle():
+    """PPO(quad_env, fused_rollout=True): the buffer the one-launch rollout fills is consistent (GAE of its own rewards / values / dones), the
+    stored log-probs and values are those of the fp32 policy the update differentiates (ratio == 1 in the first epoch, as in SB3), an update runs."""
+    from oracle import oracle as O
+    env = amd.GpuWaypointEnv(512, seed=11, max_episode_steps=40)
+    algo = PPO(env, policy=fixture_policy(env.device), n_steps=96, batch_size=4096, n_epochs=2, seed=5, fused_rollout=True)
+    with torch.no_grad():
+        algo.policy.log_std.data.fill_(-1.5)
+    b = algo.collect_rollouts()
+    T, n = algo.n_steps, algo.n_steps * env.num_envs
+    with torch.no_grad():
+        values, logp, _ = algo.policy.evaluate_actions(b.obs[:T].reshape(n, -1), b.actions.reshape(n, -1))
+    assert float((logp - b.logp.reshape(n)).abs().max()) < 2e-4
+    assert float((values - b.values.reshape(n)).abs().max()) < 1e-3 * max(1.0, float(values.abs().max()))
+    d = b.dones.bool()
+    assert 0 < int(d.sum()) < n // 4 and int(d[40].sum()) > 400
+    adv_ref, _ = O.gae_reference(b.rewards.cpu().numpy(), b.values.cpu().numpy(), b.dones.cpu().numpy(), b.last_values.cpu().numpy(), 0.995, 0.9)
+    mag = gae_magnitude(b.rewards.cpu().numpy(), b.values.cpu().numpy(), b.dones.cpu().numpy(), b.last_values.cpu().numpy())
+    assert (np.abs(b.advantages.cpu().numpy() - adv_ref) / (1.0 + mag)).max() < 1e-6
+    rec = algo.train()
+    assert all(math.isfinite(x) for x in rec.values()) and rec["clip_fraction"] < 0.5
