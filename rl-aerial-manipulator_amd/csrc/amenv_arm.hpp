@@ -657,7 +657,7 @@ __device__ __forceinline__ void arm_kin_aggregates(const PT& P, const ArmParams<
 // derivatives and writes the integrated joint state jn[6][lane] (same expressions as dynamics_arm: the joint trajectories of the staged and
 // the lane kernels are bit-identical).
 template <typename T, typename PT>
-__device__ __forceinline__ void arm_kin_stage(const PT& P, const ArmParams<T>& A, int stage, const T* th0, const T* td0, const T* cmd, float* agg, float* jn,
+__device__ __forceinline__ void arm_kin_stage(const PT& P, const ArmParams<T>& A, int stage, const T* th0, const T* td0, const T* cmd, T* agg, T* jn,
                                               int lane) {
   const T h = P.h, hh = T(0.5) * h, h6 = h * T(1.0 / 6.0);
   T th[3], td[3], a[3], accp[3], accv[3];
@@ -675,15 +675,15 @@ __device__ __forceinline__ void arm_kin_stage(const PT& P, const ArmParams<T>& A
   if (stage == 3) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      jn[k * 64 + lane] = float(fma_(h6, accp[k] + td[k], th0[k]));
-      jn[(3 + k) * 64 + lane] = float(fma_(h6, accv[k] + a[k], td0[k]));
+      jn[k * 64 + lane] = fma_(h6, accp[k] + td[k], th0[k]);
+      jn[(3 + k) * 64 + lane] = fma_(h6, accv[k] + a[k], td0[k]);
     }
   }
   T g[kAggSlots];
   arm_kin_aggregates<T, PT>(P, A, th, td, a, g);
-  float* out = agg + size_t(stage) * kAggSlots * 64 + lane;
+  T* out = agg + size_t(stage) * kAggSlots * 64 + lane;
 #pragma unroll
-  for (int q = 0; q < kAggSlots; q++) out[q * 64] = float(g[q]);
+  for (int q = 0; q < kAggSlots; q++) out[q * 64] = g[q];
 }
 
 // 13 base derivatives from a stage's aggregates g.  y: position, velocity, quaternion, body rates.
@@ -725,8 +725,9 @@ __device__ __forceinline__ void arm_dyn_agg(const PT& P, const ArmParams<T>& A, 
 }
 
 // LDS hand-over of step_kernel_armk: agg [4 stages][kAggSlots][64], jn [6][64] integrated joint state, words [12][64] reset words
-struct StagedXchg {
-  const float* agg; const float* jn; const uint32_t* words; int lane;
+template <typename T>
+struct StagedXchg {   // (exchanged in the kernel's arithmetic type: the fp64 instantiation is the logic gate of this hand-over)
+  const T* agg; const T* jn; const uint32_t* words; int lane;
   __device__ __forceinline__ void sync() const {
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
@@ -738,7 +739,7 @@ constexpr int ARM_ROLE_STAGED = 5;
 // The main wave's control step of the staged kernel: mixer, ONE barrier (the stage waves have left their aggregates), RK4 on the 13 base
 // states with arm_dyn_agg, joints from the stage-3 wave.  One RK4 sub-step per control step.
 template <typename T, int NROT, int KW>
-__device__ __forceinline__ void dynamics_arm_staged(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act, const StagedXchg& x) {
+__device__ __forceinline__ void dynamics_arm_staged(const HotParams<T, NROT>& P, const ArmParams<T>& A, Env<T, KW>& e, const float* act, const StagedXchg<T>& x) {
   const float Ff = (act[0] * P.mass_f) * P.g_f;
   const T u0 = T(Ff), u1 = T(act[1] * P.mscale_f), u2 = T(act[2] * P.mscale_f), u3 = T(act[3] * P.mscale_f);
   T F = T(0), Mx = T(0), My = T(0), Mz = T(0);
@@ -756,7 +757,7 @@ __device__ __forceinline__ void dynamics_arm_staged(const HotParams<T, NROT>& P,
   T k[13], acc[13], s[13], g[kAggSlots];
   auto stage_agg = [&](int st) {
 #pragma unroll
-    for (int q = 0; q < kAggSlots; q++) g[q] = T(x.agg[(st * kAggSlots + q) * 64 + x.lane]);
+    for (int q = 0; q < kAggSlots; q++) g[q] = x.agg[(st * kAggSlots + q) * 64 + x.lane];
   };
   stage_agg(0);
   arm_dyn_agg<T>(P, A, y, F, M, g, k);
@@ -779,7 +780,7 @@ __device__ __forceinline__ void dynamics_arm_staged(const HotParams<T, NROT>& P,
   e.qw = y[6] * rn; e.qx = y[7] * rn; e.qy = y[8] * rn; e.qz = y[9] * rn;
   e.wx = y[10]; e.wy = y[11]; e.wz = y[12];
 #pragma unroll
-  for (int j = 0; j < 3; j++) { e.th[j] = T(x.jn[j * 64 + x.lane]); e.thd[j] = T(x.jn[(3 + j) * 64 + x.lane]); }
+  for (int j = 0; j < 3; j++) { e.th[j] = x.jn[j * 64 + x.lane]; e.thd[j] = x.jn[(3 + j) * 64 + x.lane]; }
 }
 
 // Parity gate of the two formulations of the right-hand side (amenv_arm_rhs): the 19 derivatives of n states [n][19] under wrench [n][4]

@@ -357,15 +357,21 @@ hipError_t launch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_
       return hipGetLastError();
     }
   }
-  if constexpr (NJ == 3 && sizeof(T) == 4) {
-    if (T_steps == 0 && e.armk) {    // one tile per 320-thread workgroup: four stage waves + main wave
+  if constexpr (NJ == 3) {
+    if (T_steps == 0 && e.armk) {
+      if constexpr (sizeof(T) == 8) {   // the fp64 logic-gate build exchanges its aggregates in fp64: > 64 KB of dynamic LDS needs the attribute
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel_armk<T, NROT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (ea != hipSuccess) return ea;
+      }    // one tile per 320-thread workgroup: four stage waves + main wave
       const dim3 g2(e.n_tiles), b2(320);
-      const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + (4 * kAggSlots + 6 + 12) * 64) * sizeof(float);   // obs rows | aggregates | joints | reset words
+      const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + 12 * 64) * sizeof(float) + size_t((4 * kAggSlots + 6) * 64) * sizeof(T);   // obs rows | reset words | aggregates, joints (T)
       if (timed) hipExtLaunchKernelGGL((step_kernel_armk<T, NROT>), g2, b2, lds2, s, e.ev_start, e.ev_stop, 0, e.blob, tb, n, io.actions, io.obs, io.reward,
                                        io.done, io.info, tl, P, C, AA);
       else hipLaunchKernelGGL((step_kernel_armk<T, NROT>), g2, b2, lds2, s, e.blob, tb, n, io.actions, io.obs, io.reward, io.done, io.info, tl, P, C, AA);
       return hipGetLastError();
     }
+  }
+  if constexpr (NJ == 3 && sizeof(T) == 4) {
     if (T_steps == 0 && e.arm2w) {   // one tile per 128-thread workgroup: main + helper wave
       const dim3 g2(e.n_tiles), b2(128);
       const size_t lds2 = size_t(64 * ObsDim<VAR, NJ>::value + (kArmXchgSlots + 12) * 64) * sizeof(float);   // obs rows | RK4 exchange | reset words
@@ -633,9 +639,13 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // 10.6 at 32768; level from 36864 (10.6 vs 10.8) to 49152; a CU holds three of its workgroups (49 KB of LDS each), so above 49152 envs the
   // launch takes a second round of workgroups: 14.4 vs 11.8 us at 53248
   e->armk = armk_ok && (want == AMENV_KERNEL_AUTO ? (cfg->num_envs > kTeamAutoMax && cfg->num_envs <= kArmkAutoMax) : want == AMENV_KERNEL_STAGED);
+  // fp64 logic-gate build of the SAME kernel (aggregates exchanged in fp64 through LDS): opt-in only
+  if (cfg->dtype == AMENV_F64 && cfg->vehicle.n_joints == 3 && cfg->vehicle.n_rotors == 6 && !make_arm<double>(*e).generic_axes && !is_v1(cfg) &&
+      cfg->task.num_waypoints == 1 && cfg->task.rk4_substeps == 1 && want == AMENV_KERNEL_STAGED)
+    e->armk = true;
   if (want == AMENV_KERNEL_STAGED && !e->armk) {
     amenv_destroy(e);
-    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_STAGED is built for the fp32 6-rotor vehicle with the z,x,x arm, the single-waypoint v2 task "
+    return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: AMENV_KERNEL_STAGED is built for the 6-rotor vehicle with the z,x,x arm (fp64 = logic-gate build), the single-waypoint v2 task "
                 "and rk4_substeps = 1");
   }
   if (e->team || e->armk) e->arm2w = false;
@@ -682,7 +692,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   else if (e->quadk) std::snprintf(buf, sizeof(buf), "step_kernel_quad<NROT=%d,v2> (4 lanes per env, 16 envs per wave + episode-end helper wave)", cfg->vehicle.n_rotors);
   else if (e->team) std::snprintf(buf, sizeof(buf), "step_kernel_team<%s,NROT=6,v2+arm3> (16 lanes per env: 4 RK4 stages x 4 components, 4 envs per wave + episode-end helper wave)",
                                   cfg->dtype == AMENV_F64 ? "double" : "float");
-  else if (e->armk) std::snprintf(buf, sizeof(buf), "step_kernel_armk<float,NROT=6> block=320 (4 RK4 stage waves + main wave per 64-env tile)");
+  else if (e->armk) std::snprintf(buf, sizeof(buf), "step_kernel_armk<%s,NROT=6> block=320 (4 RK4 stage waves + main wave per 64-env tile)", cfg->dtype == AMENV_F64 ? "double" : "float");
   else if (e->arm2w) std::snprintf(buf, sizeof(buf), "step_kernel_arm2w<float,NROT=6> block=128 (2 waves per 64-env tile)");
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,

@@ -781,14 +781,14 @@ __global__ __launch_bounds__(320) void step_kernel_armk(void* __restrict__ blob,
                                                         float* __restrict__ obs, void* __restrict__ reward_out, uint8_t* __restrict__ done,
                                                         uint32_t* __restrict__ info, const StepTail tl, const HotParams<T, NROT> P, const ColdParams C,
                                                         const ArmArg<T, 3> AA) {
-  static_assert(sizeof(T) == 4, "fp32 kernel");
-  constexpr int KW = 1, VAR = VAR_V2, NJ = 3;
+  constexpr int KW = 1, VAR = VAR_V2, NJ = 3;   // (T = double: the logic-gate build of the same kernel, aggregates exchanged in fp64)
   constexpr int OD = ObsDim<VAR, NJ>::value, AD = kActDim + NJ;
   const Head hd{blob, tile_bytes, n_envs};
   const StepIO io{actions, obs, reward_out, done, info, tl.terminal_obs, tl.ep_return, tl.ep_len, tl.stats};
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging | [4][kAggSlots][64] aggregates | [6][64] joints | [12][64] reset words
-  float* agg = lds + 64 * OD;
-  float* jn = agg + 4 * kAggSlots * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 rows x OD] obs staging (f32) | [4][kAggSlots][64] aggregates (T) | [6][64] joints (T) | [12][64] reset words
+  static_assert((64 * OD * sizeof(float)) % 8 == 0, "the aggregates start 8-byte aligned");
+  T* agg = reinterpret_cast<T*>(lds + 64 * OD);
+  T* jn = agg + 4 * kAggSlots * 64;
   uint32_t* words = reinterpret_cast<uint32_t*>(jn + 6 * 64);
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);   // wave-uniform: 0..3 stage waves, 4 main
@@ -822,9 +822,9 @@ __global__ __launch_bounds__(320) void step_kernel_armk(void* __restrict__ blob,
 #pragma unroll
   for (int j = 0; j < 4; j++) act[j] = ap[j];
   act[4] = act[5] = act[6] = 0.0f;
-  const StagedXchg x{agg, jn, words, lane};
+  const StagedXchg<T> x{agg, jn, words, lane};
   T reward; float o[kObsDimMax]; bool was_reset; int ep_len; float ep_ret;
-  uint32_t bits = step_lane<T, NROT, KW, VAR, NJ, ARM_ROLE_STAGED, StagedXchg>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset,
+  uint32_t bits = step_lane<T, NROT, KW, VAR, NJ, ARM_ROLE_STAGED, StagedXchg<T>>(P, C, AA, e, act, i, active, reward, o, io, tile, lane, false, was_reset,
                                                                              ep_len, ep_ret, x);
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   accumulate_stats(io.stats, int(blockIdx.x), bits, is_done, ep_len, ep_ret);

@@ -99,7 +99,8 @@ def test_arm_dims_and_reset():
 # fp32 vs fp64 oracle: rounding level, far inside the 1e-5 gate; fp64 build: the logic gate; "team" = the lane-team kernel (16 lanes per env),
 # "staged" = the stage-wave kernel (four RK4 stage waves + main wave per tile, base dynamics on joint-configuration aggregates)
 @pytest.mark.parametrize("dtype,tol,kernel", [("f32", 2e-6, "lane"), ("f32", 2e-6, "helper"), ("f32", 3e-6, "team"), ("f32", 3e-6, "staged"), ("f64", 1e-12, "lane"),
-                                               ("f64", 1e-12, "team")])   # fp64 build of the lane-team kernel: the logic gate of its DPP plumbing (selectors, row sums, stage hand-over)
+                                               ("f64", 1e-12, "team"),     # fp64 build of the lane-team kernel: the logic gate of its DPP plumbing (selectors, row sums, stage hand-over)
+                                               ("f64", 1e-12, "staged")])  # fp64 build of the stage-wave kernel: the logic gate of its LDS hand-over (stage -> slot map, joint integration on wave 3)
 def test_arm_closed_loop_vs_oracle(dtype, tol, kernel):
     """Teacher-forced per step (the oracle is re-seated on the GPU state each step), joints slewing, with resets."""
     import rl_aerial_manipulator_amd as amd
