@@ -86,6 +86,17 @@ def launch_children(args):
     return 0
 
 
+def baseline_config(vehicle, n, world):
+    """Which entry of BASELINE.json's `configs` a run is."""
+    if vehicle == "hexa" and n == 4096 and world == 1:
+        return "configs[1]: 4096 parallel envs, hexacopter-only 6-DOF rigid body + 6-rotor mixer, RK4, fp32, 1xMI355X"
+    if vehicle == "hexa_arm" and n == 4096:
+        return "configs[2]: 4096 envs, hexacopter + 3-link arm coupled dynamics + waypoint reward + reset masks" + (", 1xMI355X" if world == 1 else f", x{world} MI355X (the metric's 1, 2, 4, 8 sweep)")
+    if vehicle == "hexa_arm" and n == 32768:
+        return f"configs[3]: {n * world} envs sharded {world}xMI355X (32768/GPU, embarrassingly parallel, no collectives on step path)"
+    return None
+
+
 def make_actions(torch, kind, n, ring, device, seed, act_dim=4):
     """SURVEY 8d action sets.  hover (B): thrust ~ N(1, 0.1), moments ~ N(0, 0.1), joint commands ~ N(0, 0.3), clipped to the action
     box -- long episodes with a steady trickle of crashes / resets.  uniform (A): i.i.d. U(low, high) -- tumbling, frequent resets."""
@@ -286,7 +297,8 @@ def main_worker(args):
         "config": {"workload": (f"{n} envs/GPU, " + ("hexacopter + 3-link arm coupled dynamics (19 states, 7-D action) + arm forward kinematics" if args.vehicle == "hexa_arm"
                                                        else f"{args.vehicle} 6-DOF rigid body") +
                                 f", rotor mixer, RK4 dt=5ms, waypoint reward + reach/hold state machine + termination + "
-                                f"auto-reset masks + {env.obs_dim}-D obs, one launch per control step") if not dry else "dry-run",
+                                f"auto-reset masks + {29 if args.vehicle == 'hexa_arm' else 20}-D obs, one launch per control step") + (" [dry-run: no kernel]" if dry else ""),
+                   "baseline_config": baseline_config(args.vehicle, n, world),
                    "envs_per_gpu": n, "global_envs": total_envs, "vehicle": args.vehicle, "launch_mode": launch_mode,
                    "graph_steps": plan["chunk"], "graph_replays_per_window": plan["full"] + (1 if plan["rem"] else 0),
                    "eager_launches_per_window": 0 if use_graph else K, "kernel": env.kernel_name,

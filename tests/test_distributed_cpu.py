@@ -107,3 +107,27 @@ def test_bench_gpus_n_starts_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--vehicle", "nonsense"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=280)
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_config4_line_and_ppo_bench_launcher():
+    """BASELINE configs[3] / [4] without hardware: `bench.py --gpus 8 --envs-per-gpu 32768` names config 4's workload (262144 envs over 8 ranks, no
+    step-path collective) and `tools/ppo_bench.py --gpus 2` starts its own ranks like bench.py does (children before torch / the GPU is touched,
+    no exec) and relays ONE line -- both as --dry-run over gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--envs-per-gpu", "32768", "--steps", "5", "--warmup", "1", "--dry-run", "--backend", "gloo",
+                        "--preroll", "2", "--repeats", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=560)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["config"]["global_envs"] == 262144 and out["scaling"] == "weak"
+    assert out["config"]["workload"].startswith("32768 envs/GPU, hexacopter + 3-link arm") and out["config"]["baseline_config"].startswith("configs[3]: 262144 envs sharded 8xMI355X")
+    assert "no step-path collective" in out["config"]["parallelism"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ppo_bench.py"), "--gpus", "2", "--envs", "32768", "--iters", "2", "--dry-run", "--backend", "gloo"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_envs"] == 65536 and out["config"]["grad_allreduce_bytes"] == 4 * 30537
+    assert out["minibatches_per_iter"] == 12 * 16
