@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--save", default="waypoint_controller_gpu")         # rl_train.py:57
     ap.add_argument("--vehicle", default="quad")
     ap.add_argument("--moment-scale", type=float, default=None, help="N m per unit moment action (amenv_vehicle.moment_scale; the reference quadrotor: 0.1)")
+    ap.add_argument("--warm-start-pid", type=int, default=None, metavar="DAGGER_ROUNDS",
+                    help="initialise the actor by behaviour cloning of the PID + minimum-snap baseline (amd.clone_pid_policy; 0 = plain cloning, k = k DAgger rounds). "
+                         "Needed for the hexacopter vehicles: from SB3's default initialisation PPO does not leave the free-fall plateau there (profiles/r03/ppo_hexa_sweep_*.json)")
     a = ap.parse_args()
     import torch
     import rl_aerial_manipulator_amd as amd
@@ -45,6 +48,13 @@ def main():
                     gae_lambda=0.9, clip_range=0.2, ent_coef=1e-4 if a.resume else 5e-4, dist=dist)
     if a.resume:
         model.load_policy(a.resume)
+    elif a.warm_start_pid is not None:
+        mse = amd.clone_pid_policy(env, model.policy, dagger_rounds=a.warm_start_pid)
+        if dist is not None:        # every rank cloned on its own shard: continue from rank 0's actor
+            for p_ in model.policy.parameters():
+                dist.broadcast(p_.data, src=0)
+        if sh.rank == 0:
+            print(f"warm start: actor cloned from PidWaypointPolicy (mse {mse:.4f}, {a.warm_start_pid} DAgger rounds), log_std = -1", flush=True)
     show = (lambda r: print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)) if sh.rank == 0 else None
     model.learn(a.timesteps, log_fn=show)
     if sh.rank == 0:

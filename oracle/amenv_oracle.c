@@ -344,6 +344,7 @@ void orc_arm_dynamics_step(const amenv_config* cfg, double* s, const float* acti
   for (int i = 0; i < 3; i++) for (int r = 0; r < n; r++) M[i] += v->mix[(1 + i) * n + r] * T[r];
   double cmd[3];
   for (int k = 0; k < 3; k++) {   /* action -1..1 -> joint range; formed in fp32 like the other action scalings */
+    if (k >= v->n_joints) { cmd[k] = 0.0; continue; }   /* an arm with fewer joints has fewer action entries */
     const float lo = (float)v->joint_limit[2 * k], hi = (float)v->joint_limit[2 * k + 1];
     volatile float half = 0.5f * (hi - lo), mid = 0.5f * (hi + lo);
     volatile float c = fmaf(action[4 + k], half, mid);
@@ -380,7 +381,13 @@ typedef struct {
 
 static void load_env(const amenv_config* cfg, int n, const double* f, const int32_t* is, int i, env_t* e) {
   for (int k = 0; k < 13; k++) e->s[k] = f[(size_t)k * n + i];
-  for (int k = 0; k < 6; k++) e->s[13 + k] = cfg->vehicle.n_joints ? f[(size_t)(AMENV_F_WP0 + 3 * cfg->task.num_waypoints + k) * n + i] : 0.0;
+  { /* joint fields follow the waypoints: th[0..nj) then thd[0..nj) (enum amenv_float_field); absent joints stay 0 */
+    const int nj = cfg->vehicle.n_joints, j0 = AMENV_F_WP0 + 3 * cfg->task.num_waypoints;
+    for (int k = 0; k < 3; k++) {
+      e->s[13 + k] = k < nj ? f[(size_t)(j0 + k) * n + i] : 0.0;
+      e->s[16 + k] = k < nj ? f[(size_t)(j0 + nj + k) * n + i] : 0.0;
+    }
+  }
   e->final_yaw = f[(size_t)AMENV_F_FINAL_YAW * n + i];
   e->last_distance = f[(size_t)AMENV_F_LAST_DISTANCE * n + i];
   e->ep_return = f[(size_t)AMENV_F_EP_RETURN * n + i];
@@ -395,7 +402,10 @@ static void load_env(const amenv_config* cfg, int n, const double* f, const int3
 
 static void store_env(const amenv_config* cfg, int n, double* f, int32_t* is, int i, const env_t* e) {
   for (int k = 0; k < 13; k++) f[(size_t)k * n + i] = e->s[k];
-  if (cfg->vehicle.n_joints) for (int k = 0; k < 6; k++) f[(size_t)(AMENV_F_WP0 + 3 * cfg->task.num_waypoints + k) * n + i] = e->s[13 + k];
+  {
+    const int nj = cfg->vehicle.n_joints, j0 = AMENV_F_WP0 + 3 * cfg->task.num_waypoints;
+    for (int k = 0; k < nj; k++) { f[(size_t)(j0 + k) * n + i] = e->s[13 + k]; f[(size_t)(j0 + nj + k) * n + i] = e->s[16 + k]; }
+  }
   f[(size_t)AMENV_F_FINAL_YAW * n + i] = e->final_yaw;
   f[(size_t)AMENV_F_LAST_DISTANCE * n + i] = e->last_distance;
   f[(size_t)AMENV_F_EP_RETURN * n + i] = e->ep_return;

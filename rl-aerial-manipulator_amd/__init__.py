@@ -14,6 +14,6 @@ from .vec_env import GpuVecEnv
 from .obs_norm import GpuVecNormalize, ObsNormalizer
 from . import baselines, ppo
 from .baselines import MinSnapTrajectory, PidController, PidWaypointPolicy
-from .ppo import PPO, ActorCritic, evaluate_policy
+from .ppo import PPO, ActorCritic, evaluate_policy, clone_pid_policy
 
-__all__ = ["GpuWaypointEnv", "GpuVecEnv", "GpuVecNormalize", "ObsNormalizer", "PPO", "ActorCritic", "evaluate_policy", "ppo", "baselines", "PidController", "MinSnapTrajectory", "PidWaypointPolicy", "vec_env", "AmenvError", "_lib", "sharding"]
+__all__ = ["GpuWaypointEnv", "GpuVecEnv", "GpuVecNormalize", "ObsNormalizer", "PPO", "ActorCritic", "evaluate_policy", "clone_pid_policy", "ppo", "baselines", "PidController", "MinSnapTrajectory", "PidWaypointPolicy", "vec_env", "AmenvError", "_lib", "sharding"]

@@ -48,6 +48,13 @@ struct amenv {
   bool quad_ok = false;            // fp32 rigid vehicle with 4 or 6 rotors, single-waypoint v2 task: lane-quad kernels (step opt-in, closed-loop rollout)
   bool team_ok = false;            // the configuration has a team kernel (fp32, 6 rotors, z,x,x arm): constants are allocated
   uint32_t* pol_pack = nullptr;    // amenv_rollout_policy: policy parameters as MFMA fragments (re-packed on every call)
+  // n-link arm with n < 3 (amenv_vehicle.n_joints = 1 or 2): inside, the vehicle is the 3-joint one with PHANTOM links behind the real ones (zero
+  // mass / inertia / offset, joint limits 0 -> command 0, state 0: every term they add is an exact zero), so every kernel family serves it;
+  // the C ABI keeps the caller's dimensions (4 + n actions, 20 + 2 n + 3 observations, 2 n joint fields): pack / unpack kernels at the boundary
+  int pub_nj = 0;                  // the caller's n_joints (cfg.vehicle.n_joints is the internal 3 when this is 1 or 2)
+  float* io_act = nullptr;         // [N][7]   padded actions
+  float* io_obs = nullptr;         // [N][29]  internal observation rows
+  float* io_term = nullptr;        // [N][29]  internal terminal-observation rows
   uint64_t steps = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // amenv_step_timed only
   std::string err;
@@ -302,9 +309,9 @@ const char* validate(const amenv_config* c) {
   if (c->num_envs <= 0) return "num_envs must be > 0";
   if (c->dtype != AMENV_F32 && c->dtype != AMENV_F64) return "dtype must be AMENV_F32 or AMENV_F64";
   if (c->vehicle.n_rotors < 1 || c->vehicle.n_rotors > AMENV_MAX_ROTORS) return "n_rotors out of range";
-  if (c->vehicle.n_joints != 0 && c->vehicle.n_joints != 3) return "n_joints must be 0 or 3";
-  if (c->vehicle.n_joints == 3 && (c->vehicle.n_rotors != 6 || c->task.num_waypoints != 1 || is_v1(c)))
-    return "the arm vehicle is built for the 6-rotor airframe, the v2 task and 1 waypoint (BASELINE config 3)";
+  if (c->vehicle.n_joints < 0 || c->vehicle.n_joints > AMENV_MAX_JOINTS) return "n_joints must be 0..3";
+  if (c->vehicle.n_joints > 0 && (c->vehicle.n_rotors != 6 || c->task.num_waypoints != 1 || is_v1(c)))
+    return "arm vehicles are built for the 6-rotor airframe, the v2 task and 1 waypoint (BASELINE config 3)";
   if (c->task.variant != AMENV_TASK_V2_SCALED20 && !is_v1(c)) return "unknown task variant";
   if (is_v1(c) && c->task.num_waypoints > 2) return "v1 tasks draw 1..2 waypoints per episode: num_waypoints (storage bound) must be 1 or 2";
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
@@ -452,7 +459,7 @@ hipError_t launch_observe(const amenv& e, float* obs, float* ee, hipStream_t s) 
 template <typename T>
 hipError_t launch_transpose(const amenv& e, void* f, int32_t* i, int to_api, hipStream_t s) {
   const int bs = 256, n = e.cfg.num_envs;
-  hipLaunchKernelGGL((transpose_state_kernel<T>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, e.nf, e.cfg.task.num_waypoints, e.cfg.vehicle.n_joints, e.tile_bytes, e.blob, (T*)f, i, to_api);
+  hipLaunchKernelGGL((transpose_state_kernel<T>), dim3((n + bs - 1) / bs), dim3(bs), 0, s, n, e.nf, e.cfg.task.num_waypoints, e.pub_nj /* the caller's joint fields: th[0..n), thd[0..n) */, e.tile_bytes, e.blob, (T*)f, i, to_api);
   return hipGetLastError();
 }
 
@@ -549,6 +556,39 @@ int64_t amenv_bytes_per_env_step(const amenv_config* cfg) {
   return rd + wr;
 }
 
+// ---- n-link arm, n < 3: boundary adapters (see struct amenv) ---------------------------------------------------------------------
+namespace {
+__global__ void arm_pad_actions_kernel(const float* __restrict__ a, int n, int nj, float* __restrict__ out) {   // [N][4 + nj] -> [N][7]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 7) return;
+  const int e = i / 7, k = i % 7;
+  out[i] = k < 4 + nj ? a[e * (4 + nj) + k] : 0.0f;
+}
+// internal rows [N][29] = 20 | th(3) | thd(3) | tool(3)  ->  public rows [N][20 + 2 nj + 3]; rows_of: only rows with a non-zero byte (terminal rows)
+__global__ void arm_cut_obs_kernel(const float* __restrict__ in, int n, int nj, const uint8_t* __restrict__ rows_of, float* __restrict__ out) {
+  const int od = 23 + 2 * nj;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * od) return;
+  const int e = i / od, k = i % od;
+  if (rows_of && !rows_of[e]) return;
+  const int src = k < 20 ? k : (k < 20 + nj ? k : (k < 20 + 2 * nj ? 23 + (k - 20 - nj) : 26 + (k - 20 - 2 * nj)));
+  out[i] = in[e * 29 + src];
+}
+// the 3-joint vehicle with phantom links behind the caller's n (1 or 2) real ones
+amenv_config pad_arm_config(const amenv_config& c) {
+  amenv_config p = c;
+  amenv_vehicle& v = p.vehicle;
+  for (int k = c.vehicle.n_joints; k < 3; k++) {
+    v.link_mass[k] = 0.0;
+    for (int j = 0; j < 3; j++) { v.joint_origin[3 * k + j] = 0.0; v.link_com[3 * k + j] = 0.0; v.joint_axis[3 * k + j] = j == 0 ? 1.0 : 0.0; }   // x axis: keeps a z[,x] arm on the z,x,x kernels
+    for (int j = 0; j < 9; j++) v.link_inertia[9 * k + j] = 0.0;
+    v.joint_limit[2 * k] = v.joint_limit[2 * k + 1] = 0.0;
+  }
+  v.n_joints = 3;
+  return p;
+}
+}  // namespace
+
 int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   if (!out) return fail(nullptr, AMENV_ERR_INVALID, "amenv_create: out is NULL");
   *out = nullptr;
@@ -563,9 +603,12 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
     return fail(nullptr, AMENV_ERR_NO_DEVICE, std::string("amenv_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
   amenv* e = new (std::nothrow) amenv();
   if (!e) return fail(nullptr, AMENV_ERR_ALLOC, "amenv_create: out of host memory");
-  e->cfg = *cfg;
+  const amenv_config user_cfg = *cfg;                       // the caller's dimensions (obs / action / state fields)
+  e->pub_nj = user_cfg.vehicle.n_joints;
+  e->cfg = (e->pub_nj == 1 || e->pub_nj == 2) ? pad_arm_config(user_cfg) : user_cfg;
+  cfg = &e->cfg;                                            // everything below sets up the (internal) vehicle the kernels run
   e->device = device;
-  e->nf = n_float_fields(cfg);
+  e->nf = n_float_fields(&user_cfg);
   const size_t n = size_t(cfg->num_envs), ts = cfg->dtype == AMENV_F64 ? 8 : 4;
   e->fbytes = size_t(e->nf) * n * ts;
   e->ibytes = size_t(AMENV_I_NFIELDS) * n * sizeof(int32_t);
@@ -697,8 +740,19 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   else std::snprintf(buf, sizeof(buf), "step_kernel<%s,NROT=%d,KW=%d,%s> block=%d", cfg->dtype == AMENV_F64 ? "double" : "float",
                 (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) ? cfg->vehicle.n_rotors : AMENV_MAX_ROTORS,
                 is_v1(cfg) ? 2 : (cfg->task.num_waypoints == 1 ? 1 : AMENV_MAX_WAYPOINTS), cfg->vehicle.n_joints ? "v2+arm3" : (is_v1(cfg) ? "v1" : "v2"), e->block);
-  e->obs_dim = obs_dim_of(cfg);
-  e->act_dim = act_dim_of(cfg);
+  e->obs_dim = obs_dim_of(&user_cfg);
+  e->act_dim = act_dim_of(&user_cfg);
+  if (e->pub_nj == 1 || e->pub_nj == 2) {
+    if ((s = hipMalloc((void**)&e->io_act, n * 7 * sizeof(float))) != hipSuccess || (s = hipMalloc((void**)&e->io_obs, n * 29 * sizeof(float))) != hipSuccess ||
+        (s = hipMalloc((void**)&e->io_term, n * 29 * sizeof(float))) != hipSuccess) {
+      std::string msg = std::string("amenv_create: n-link adapter buffers: ") + hipGetErrorString(s);
+      amenv_destroy(e);
+      return fail(nullptr, AMENV_ERR_ALLOC, msg);
+    }
+    buf[sizeof(buf) - 1] = 0;
+    std::string kn = std::string(buf) + " [" + std::to_string(e->pub_nj) + "-joint arm: phantom links inside, pack / unpack at the C ABI]";
+    std::snprintf(buf, sizeof(buf), "%s", kn.c_str());
+  }
   e->kname = buf;
   *out = e;
   return AMENV_OK;
@@ -712,6 +766,9 @@ int amenv_destroy(amenv* e) {
     if (e->stats) (void)hipFree(e->stats);
     if (e->team_consts) (void)hipFree(e->team_consts);
     if (e->pol_pack) (void)hipFree(e->pol_pack);
+    if (e->io_act) (void)hipFree(e->io_act);
+    if (e->io_obs) (void)hipFree(e->io_obs);
+    if (e->io_term) (void)hipFree(e->io_term);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
   }
@@ -721,6 +778,19 @@ int amenv_destroy(amenv* e) {
 
 const char* amenv_last_error(const amenv* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 const char* amenv_kernel_name(const amenv* e) { return e ? e->kname.c_str() : ""; }
+
+namespace {
+hipError_t pad_actions(const amenv& e, const float* actions, hipStream_t s) {
+  const int n = e.cfg.num_envs;
+  hipLaunchKernelGGL(arm_pad_actions_kernel, dim3((n * 7 + 255) / 256), dim3(256), 0, s, actions, n, e.pub_nj, e.io_act);
+  return hipGetLastError();
+}
+hipError_t cut_obs(const amenv& e, const float* rows29, const uint8_t* rows_of, float* out, hipStream_t s) {
+  const int n = e.cfg.num_envs, od = 23 + 2 * e.pub_nj;
+  hipLaunchKernelGGL(arm_cut_obs_kernel, dim3((n * od + 255) / 256), dim3(256), 0, s, rows29, n, e.pub_nj, rows_of, out);
+  return hipGetLastError();
+}
+}  // namespace
 
 int amenv_set_seed(amenv* e, uint64_t seed) {
   if (!e) return AMENV_ERR_INVALID;
@@ -732,7 +802,9 @@ int amenv_reset(amenv* e, const uint8_t* mask, float* obs_out, void* stream) {
   if (!e) return AMENV_ERR_INVALID;
   DeviceGuard g(e->device);
   hipStream_t s = (hipStream_t)stream;
-  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_reset<double>(*e, mask, obs_out, 0, s) : launch_reset<float>(*e, mask, obs_out, 0, s));
+  float* o = (e->io_obs && obs_out) ? e->io_obs : obs_out;
+  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_reset<double>(*e, mask, o, 0, s) : launch_reset<float>(*e, mask, o, 0, s));
+  if (o != obs_out) AMENV_HIP(e, cut_obs(*e, e->io_obs, nullptr, obs_out, s));
   return AMENV_OK;
 }
 
@@ -740,7 +812,9 @@ int amenv_observe(amenv* e, float* obs_out, void* stream) {
   if (!e || !obs_out) return fail(e, AMENV_ERR_INVALID, "amenv_observe: NULL argument");
   DeviceGuard g(e->device);
   hipStream_t s = (hipStream_t)stream;
-  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_observe<double>(*e, obs_out, nullptr, s) : launch_observe<float>(*e, obs_out, nullptr, s));
+  float* o = e->io_obs ? e->io_obs : obs_out;
+  AMENV_HIP(e, e->cfg.dtype == AMENV_F64 ? launch_observe<double>(*e, o, nullptr, s) : launch_observe<float>(*e, o, nullptr, s));
+  if (o != obs_out) AMENV_HIP(e, cut_obs(*e, e->io_obs, nullptr, obs_out, s));
   return AMENV_OK;
 }
 
@@ -759,10 +833,12 @@ int amenv_step(amenv* e, const float* actions, float* obs, void* reward, uint8_t
   if (!aligned16(actions) || !aligned16(obs) || (terminal_obs && !aligned16(terminal_obs)))
     return fail(e, AMENV_ERR_INVALID, "amenv_step: actions/obs/terminal_obs must be 16-byte aligned");
   DeviceGuard g(e->device);
-  StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, terminal_obs, ep_return, ep_len, e->stats};
   hipStream_t s = (hipStream_t)stream;
+  StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, terminal_obs, ep_return, ep_len, e->stats};
+  if (e->io_act) { AMENV_HIP(e, pad_actions(*e, actions, s)); io.actions = reinterpret_cast<const float4*>(e->io_act); io.obs = e->io_obs; io.terminal_obs = terminal_obs ? e->io_term : nullptr; }
   hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, 0, s, false) : dispatch_step<float>(*e, io, 0, s, false);
   AMENV_HIP(e, st);
+  if (e->io_act) { AMENV_HIP(e, cut_obs(*e, e->io_obs, nullptr, obs, s)); if (terminal_obs) AMENV_HIP(e, cut_obs(*e, e->io_term, done, terminal_obs, s)); }
   e->steps += uint64_t(e->cfg.num_envs);
   return AMENV_OK;
 }
@@ -777,8 +853,10 @@ int amenv_step_timed(amenv* e, const float* actions, float* obs, void* reward, u
   if (!e->ev_start) { AMENV_HIP(e, hipEventCreate(&e->ev_start)); AMENV_HIP(e, hipEventCreate(&e->ev_stop)); }
   StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, terminal_obs, ep_return, ep_len, e->stats};
   hipStream_t s = (hipStream_t)stream;
+  if (e->io_act) { AMENV_HIP(e, pad_actions(*e, actions, s)); io.actions = reinterpret_cast<const float4*>(e->io_act); io.obs = e->io_obs; io.terminal_obs = terminal_obs ? e->io_term : nullptr; }
   hipError_t st = e->cfg.dtype == AMENV_F64 ? dispatch_step<double>(*e, io, 0, s, true) : dispatch_step<float>(*e, io, 0, s, true);
   AMENV_HIP(e, st);
+  if (e->io_act) { AMENV_HIP(e, cut_obs(*e, e->io_obs, nullptr, obs, s)); if (terminal_obs) AMENV_HIP(e, cut_obs(*e, e->io_term, done, terminal_obs, s)); }
   AMENV_HIP(e, hipEventSynchronize(e->ev_stop));
   float ms = 0.f;
   AMENV_HIP(e, hipEventElapsedTime(&ms, e->ev_start, e->ev_stop));
@@ -793,6 +871,7 @@ int amenv_rollout(amenv* e, int32_t n_steps, const float* actions, float* obs, v
   if (n_steps <= 0 || !actions) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: n_steps must be > 0 and actions non-NULL");
   if (!aligned16(actions) || (obs && !aligned16(obs))) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: actions/obs must be 16-byte aligned");
   if (e->team && e->cfg.dtype == AMENV_F64) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: the fp64 lane-team build is a logic gate of amenv_step only");
+  if (e->io_act) return fail(e, AMENV_ERR_INVALID, "amenv_rollout: arms with 1 or 2 joints are served through amenv_step (the adapters at the C ABI are per step)");
   DeviceGuard g(e->device);
   StepIO io{reinterpret_cast<const float4*>(actions), obs, reward, done, info_bits, nullptr, nullptr, nullptr, e->stats};
   hipStream_t s = (hipStream_t)stream;
@@ -808,6 +887,7 @@ int amenv_rollout_policy(amenv* e, int32_t n_steps, const float* flat_params, ui
   if (!e->team_ok && !e->quad_ok)
     return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: built for fp32 vehicles on the single-waypoint v2 task: rigid with 4 or 6 rotors (default workgroup size), or the "
                 "6-rotor vehicle with the z,x,x arm");
+  if (e->io_act) return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: arms with 1 or 2 joints are served through amenv_step");
   if (n_steps <= 0 || !flat_params || !obs || !actions || !logp || !values || !rewards || !dones)
     return fail(e, AMENV_ERR_INVALID, "amenv_rollout_policy: n_steps must be > 0 and flat_params / obs / actions / logp / values / rewards / dones non-NULL");
   DeviceGuard g(e->device);

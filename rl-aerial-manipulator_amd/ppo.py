@@ -742,6 +742,56 @@ class PPO:
 
 
 @torch.no_grad()
+def clone_pid_policy(env, policy, steps=600, epochs=400, dagger_rounds=0, noise=0.15, initial_log_std=-1.0, seed=1):
+    """Warm start for `PPO`: fit the actor's mean to `PidWaypointPolicy` (the reference's PID + minimum-snap baseline, HIP kernels) by behaviour
+    cloning on states the PID visits (exploration noise on the executed actions, so that the data covers recoveries); with `dagger_rounds` > 0
+    the STUDENT then flies while the PID labels the states it reaches, and the actor is refitted on everything collected (DAgger).  Sets
+    log_std to `initial_log_std`.  Returns the final MSE.
+
+    Why: with SB3's default initialisation PPO (the reference's hyper-parameters, v2/rl_train.py:38-53) leaves the free-fall plateau on the
+    reference's quadrotor after ~35 M steps but not on the hexacopter within 150 M -- whatever its moment scaling, rotor limits, inertia,
+    exploration noise or thrust bias (profiles/r03/ppo_hexa_sweep_*.json); from a cloned actor -- even one that does not yet reach a single
+    waypoint itself -- it reaches > 90 % success on the hexacopter in ~55 M steps and on the hexacopter + arm (tool-point task) in 35-77 M."""
+    from .baselines import PidWaypointPolicy
+    pid = PidWaypointPolicy.for_env(env)
+    g = torch.Generator(device=env.device).manual_seed(seed)
+    X, Y = [], []
+
+    def collect(student):
+        obs = env.reset()
+        done = None
+        if pid.pstate is not None:
+            pid.pstate[:, 13] = 1.0          # every env starts a fresh episode (new minimum-snap segment)
+        for _ in range(steps):
+            a = pid.predict(obs, done)
+            X.append(obs.clone()); Y.append(a.clone())
+            fly = policy.actor(obs) if student else a
+            noisy = fly + noise * torch.randn(a.shape, device=a.device, generator=g)
+            obs, _, done, _ = env.step(torch.max(torch.min(noisy, policy.action_high), policy.action_low))
+
+    def fit():
+        Xc, Yc = torch.cat(X), torch.cat(Y)
+        opt = torch.optim.Adam(list(policy.mlp_extractor.policy_net.parameters()) + list(policy.action_net.parameters()), lr=1e-3)
+        loss = None
+        for _ in range(epochs):
+            idx = torch.randint(0, Xc.shape[0], (min(16384, Xc.shape[0]),), device=Xc.device)
+            with torch.enable_grad():
+                loss = ((policy.actor(Xc[idx]) - Yc[idx]) ** 2).mean()
+                opt.zero_grad(); loss.backward(); opt.step()
+        return float(loss.detach())
+
+    with torch.no_grad():
+        collect(False)
+    mse = fit()
+    for _ in range(int(dagger_rounds)):
+        with torch.no_grad():
+            collect(True)
+        mse = fit()
+    with torch.no_grad():
+        policy.log_std.data.fill_(float(initial_log_std))
+    return mse
+
+
 def evaluate_policy(model, env, n_eval_episodes=10, deterministic=True, check_every=64, max_steps=None):
     """SB3 `evaluate_policy(model, env, n_eval_episodes)` (v2/rl_train.py:60) on the batched env: every env contributes the
     same number of episodes (ceil(n / num_envs), SB3's rule for vectorised envs), returns (mean, std) of the episode returns.

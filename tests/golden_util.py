@@ -48,3 +48,17 @@ def fill_blob(fstate, istate, d, K=1, per_env_k=False):
         tf["counter_activated"], O.FLAGBIT_COUNTER_ACTIVE, 0)
     istate[O.I_EPISODE, :T] = 1
     return tf
+
+
+def report_flips(where, flips, out_of):
+    """fp32 threshold flips (a comparison such as d < 0.1 taken differently from the fp64 oracle because the oracle's own margin is below the fp32
+    tolerance): the count a parity test tolerated, printed and appended to gpurun_out/threshold_flips.txt (DESIGN section 2 quotes that file)."""
+    line = f"{where}: {int(flips)} of {int(out_of)}"
+    print("threshold flips --", line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "threshold_flips.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass

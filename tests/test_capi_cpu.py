@@ -33,6 +33,11 @@ def test_struct_layout_matches_header():
     od = C.c_int32(); ad = C.c_int32()
     amd._lib.load().amenv_dims(C.byref(arm), C.byref(od), C.byref(ad), None, None)
     assert (od.value, ad.value) == (29, 7)
+    nf = C.c_int32()
+    for nj in (1, 2):       # an n-link arm with fewer joints keeps ITS dimensions at the C ABI: 4 + n actions, 20 + 2 n + 3 observations, 2 n joint fields
+        arm.vehicle.n_joints = nj
+        amd._lib.load().amenv_dims(C.byref(arm), C.byref(od), C.byref(ad), C.byref(nf), None)
+        assert (od.value, ad.value, nf.value) == (23 + 2 * nj, 4 + nj, 19 + 2 * nj)
 
 
 def test_pid_default_params_are_the_reference_gains():

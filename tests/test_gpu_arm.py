@@ -133,8 +133,10 @@ def test_arm_closed_loop_vs_oracle(dtype, tol, kernel):
         dn = ok & (o["done"] != 0)
         dones += int(dn.sum())
         assert np.array_equal(f2[:, dn], orc.fstate[:, dn]) and np.array_equal(i2[:, ok], orc.istate[:, ok])
+    from tests.golden_util import report_flips
+    report_flips(f"test_arm_closed_loop_vs_oracle[{dtype}-{kernel}] (flag bits vs the oracle, env-steps)", flips, 150 * n)
     assert worst < tol, worst
-    assert worst_obs < max(tol, 1.3e-7) and flips <= 4 and dones > 100, (worst_obs, flips, dones)
+    assert worst_obs < max(tol, 1.3e-7) and flips <= 4 and dones > 100, f"obs {worst_obs}, {flips} threshold flips in {150 * n} env-steps, {dones} episode ends"
     env.close()
 
 
@@ -567,3 +569,62 @@ def test_arm_rk4_substeps_vs_oracle(substeps, kernel, n):
     f1, _ = gpu_state(one); f2_, _ = gpu_state(sub)
     d = np.abs(f1[:13] - f2_[:13]).max()
     assert 0 < d < 1e-6, d          # same motion to integration error, not bit for bit
+
+
+@pytest.mark.parametrize("nj,dtype,kernel,tol", [(1, "f64", "lane", 1e-12), (2, "f64", "lane", 1e-12), (2, "f64", "team", 1e-12), (1, "f32", "team", 3e-6), (2, "f32", "auto", 3e-6),
+                                                 (2, "f32", "staged", 3e-6), (1, "f32", "helper", 3e-6)])
+def test_n_link_arm_with_fewer_joints(nj, dtype, kernel, tol):
+    """north_star's "n-link arm": amenv_vehicle.n_joints = 1 or 2.  Inside, the vehicle is the 3-joint one with phantom links behind the real
+    ones (zero mass / inertia / offset: exact zeros in every sum), so EVERY kernel family serves it; the C ABI keeps the caller's dimensions
+    (4 + n actions, 20 + 2 n + 3 observations, 2 n joint state fields).  Teacher-forced per step against the oracle, which runs the SHORTER chain
+    natively: fp64 builds <= 1e-12 (the phantom links add nothing), fp32 to rounding; reset states bit-exact; amenv_rollout refuses."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n = 777
+    rng = np.random.RandomState(10 * nj + len(kernel))
+    lm = [0.082, 0.054, 0.220]
+    mass = 3.2121 - sum(lm[nj:])
+    cfg = amd._lib.default_config("hexa_arm", n)
+    cfg.vehicle.n_joints = nj; cfg.vehicle.mass = mass
+    cfg.seed = 9; cfg.task.max_episode_steps = 100
+    cfg.dtype = amd._lib.F64 if dtype == "f64" else amd._lib.F32
+    cfg.step_kernel = amd._lib.KERNELS[kernel]
+    env = amd.GpuWaypointEnv(n, config=cfg)
+    assert (env.obs_dim, env.act_dim, env.n_float_fields) == (23 + 2 * nj, 4 + nj, 19 + 2 * nj) and f"{nj}-joint arm" in env.kernel_name
+    orc = orc_arm(n, seed=9, n_joints=nj, mass=mass)
+    orc.cfg.task.max_episode_steps = 100
+    obs0 = env.reset().cpu().numpy(); oobs0 = orc.reset()
+    f, i = gpu_state(env)
+    assert np.array_equal(f, orc.fstate) and np.array_equal(i, orc.istate)
+    np.testing.assert_allclose(obs0, oobs0, rtol=OBS_ULP, atol=1.5e-7)
+    np.testing.assert_allclose(env.observe().cpu().numpy(), oobs0, rtol=OBS_ULP, atol=1.5e-7)
+    np.testing.assert_allclose(env.ee_position().cpu().numpy(), orc.ee_position(), rtol=0, atol=3e-7)
+    q = rng.normal(size=(4, n)) * 0.2; q[0] += 1; q /= np.linalg.norm(q, axis=0)
+    f[6:10] = q; f[10:13] = rng.normal(0, 1.0, (3, n)); f[3:6] = rng.normal(0, 0.5, (3, n))
+    f[19:19 + nj] = rng.uniform(-1, 1, (nj, n)); f[19 + nj:19 + 2 * nj] = rng.normal(0, 1.0, (nj, n))
+    env.set_state(f if dtype == "f64" else f.astype(np.float32), i)
+    worst = 0.0; worst_obs = 0.0; flips = 0; dones = 0
+    for t in range(130):
+        a = rng.uniform([0.6] + [-1] * (3 + nj), [1.4] + [1] * (3 + nj), (n, 4 + nj)).astype(np.float32)
+        a[:, 1:4] *= 0.05
+        a[::9, 0] = 0.0
+        g, o = both_step(env, orc, a)
+        f2, i2 = gpu_state(env)
+        bad = np.nonzero((g["info"] & 127) != (o["info"] & 127))[0]
+        flips += len(bad)
+        ok = np.ones(n, bool); ok[bad] = False
+        nd = ok & (o["done"] == 0)
+        rows = np.r_[0:15, 16:19 + 2 * nj]
+        if nd.any():            # (at the time limit every env that has not crashed yet ends in the same step)
+            worst = max(worst, rel_err(f2[rows][:, nd], orc.fstate[rows][:, nd]).max())
+        worst_obs = max(worst_obs, rel_err(g["obs"][ok], o["obs"][ok]).max())
+        dn = ok & (o["done"] != 0)
+        dones += int(dn.sum())
+        assert np.array_equal(f2[:, dn], orc.fstate[:, dn]) and np.array_equal(i2[:, ok], orc.istate[:, ok])
+        if dn.any():
+            tob = env.terminal_obs.cpu().numpy()
+            assert np.isfinite(tob[dn]).all() and tob.shape[1] == 23 + 2 * nj
+    assert worst < tol and worst_obs < max(tol, 1.3e-7) and flips <= 3 and dones > 50, (worst, worst_obs, flips, dones)
+    with pytest.raises(amd.AmenvError, match="1 or 2 joints|logic gate"):
+        env.rollout(torch.zeros(2, n, 4 + nj, device="cuda"))
+    env.close()

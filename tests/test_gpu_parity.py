@@ -116,7 +116,8 @@ def test_teacher_forced_golden_fp32(amd, name):
     info = info.cpu().numpy().view(np.uint32)
     wp = np.repeat(d["waypoints"][0][:, None], T, 1)
     bad = flag_mismatch_ok(dict(info=info), dict(info=d["info_bits"]), d["state"][1:].T, wp, 2e-5)
-    assert len(bad) <= max(1, T // 200), bad
+    G.report_flips(f"test_teacher_forced_golden_fp32[{name}] (flag bits vs the reference, steps)", len(bad), T)
+    assert len(bad) <= max(1, T // 200), f"{len(bad)} threshold flips in {T} steps: {bad}"
     ok = np.ones(T, bool); ok[bad] = False
     assert np.array_equal(i[O.I_STEP], d["var_current_step"][1:])
     assert np.array_equal(i[O.I_COUNTER][ok], d["var_counter"][1:][ok])
@@ -199,7 +200,8 @@ def test_random_states_vs_oracle(amd, dtype, n):
     nd = (o["done"] == 0) & (g["done"] == 0)
     assert rel_err(f[0:13][:, nd], orc.fstate[0:13][:, nd]).max() < tol
     bad = flag_mismatch_ok(g, o, o["post"], wp, 3e-5) if dtype == "f32" else np.nonzero((g["info"] & 127) != (o["info"] & 127))[0]
-    assert len(bad) <= (n // 500 if dtype == "f32" else 0), len(bad)
+    G.report_flips(f"test_random_states_vs_oracle[{dtype}-{n}] (flag bits vs the oracle, envs)", len(bad), n)
+    assert len(bad) <= (n // 500 if dtype == "f32" else 0), f"{len(bad)} threshold flips in {n} envs"
     ok = np.ones(n, bool); ok[bad] = False
     assert np.array_equal(g["done"][ok], o["done"][ok])
     # branch coverage of the random blob

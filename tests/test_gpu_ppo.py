@@ -781,3 +781,30 @@ def test_ppo_fused_rollout_on_the_reference_vehicle():
     assert (np.abs(b.advantages.cpu().numpy() - adv_ref) / (1.0 + mag)).max() < 1e-6
     rec = algo.train()
     assert all(math.isfinite(x) for x in rec.values()) and rec["clip_fraction"] < 0.5
+
+
+def test_pid_warm_start_moves_the_actor_towards_the_baseline():
+    """amd.clone_pid_policy (the warm start PPO needs on the hexacopter vehicles, profiles/r03/ppo_hexa_*): a short cloning run lowers the actor's
+    MSE against PidWaypointPolicy's actions along a PID flight, sets log_std, leaves the critic untouched, works for the arm vehicle's 29-D / 7-D
+    interface too."""
+    def mse_along_pid_flight(env, pol):
+        pid = amd.PidWaypointPolicy.for_env(env)
+        obs = env.reset(); done = None; tot = 0.0
+        with torch.no_grad():
+            for _ in range(150):
+                a = pid.predict(obs, done)
+                tot += float(((pol.actor(obs) - a) ** 2).mean())
+                obs, _, done, _ = env.step(a)
+        return tot / 150
+
+    for vehicle in ("hexa", "hexa_arm"):
+        env = amd.GpuWaypointEnv(256, vehicle=vehicle, seed=2)
+        pol = ActorCritic(env.obs_dim, env.act_dim).cuda()
+        critic0 = [p.detach().clone() for p in pol.mlp_extractor.value_net.parameters()]
+        before = mse_along_pid_flight(env, pol)
+        amd.clone_pid_policy(env, pol, steps=300, epochs=200, dagger_rounds=1)
+        after = mse_along_pid_flight(env, pol)
+        assert after < 0.7 * before, (vehicle, before, after)      # (the PID saturates its moment actions: the cloned MEAN cannot follow the chatter; measured 0.57 -> 0.31)
+        assert float(pol.log_std.data.max()) == -1.0
+        assert all(torch.equal(a, b) for a, b in zip(critic0, pol.mlp_extractor.value_net.parameters()))
+        env.close()
