@@ -56,10 +56,12 @@ extern "C" {
 #define AMENV_KERNEL_AUTO 0
 #define AMENV_KERNEL_LANE 1   /* one lane per env, one wavefront per 64-env tile                                      */
 #define AMENV_KERNEL_HELPER 2 /* LANE + helper wavefronts per tile (reset RNG words, observation rows, arm link 3)     */
-#define AMENV_KERNEL_TEAM 3   /* arm vehicle: a team of 16 lanes (one DPP row) per env, AUTO up to 8192 envs; rigid vehicles: 4 lanes (one
-                                 DPP quad) per env, opt-in only (measured no faster than HELPER)                          */
+#define AMENV_KERNEL_TEAM 3   /* arm vehicle: a team of 16 lanes (one DPP row) per env, AUTO up to 6144 envs; with AMENV_F64 the fp64 build of
+                                 the SAME kernel (logic gate of its DPP plumbing; amenv_step only); rigid vehicles: 4 lanes (one DPP quad)
+                                 per env, opt-in only (measured no faster than HELPER)                                       */
 #define AMENV_KERNEL_STAGED 4 /* arm vehicle: the four RK4 stages' joint-configuration work on four wavefronts side by side,
-                                 the base dynamics on their 36-number aggregates on a fifth (not bit-identical to LANE)  */
+                                 the base dynamics on their 36-number aggregates on a fifth (not bit-identical to LANE);
+                                 AUTO for 6145..32768 envs; with AMENV_F64 the fp64 build of the same kernel (logic gate) */
 
 /* amenv_task.ee_task (arm vehicles only; ignored without an arm) */
 #define AMENV_EE_TASK_BASE 0 /* waypoint distance measured from the base position, as the reference's quadrotor task   */
@@ -86,7 +88,8 @@ extern "C" {
  * [t_min,t_max], then [F',Mx',My',Mz']^T = mix . T   (v2/simul_files/model/quadcopter.py:109-112). */
 typedef struct amenv_vehicle {
   int32_t n_rotors; /* 1..AMENV_MAX_ROTORS */
-  int32_t n_joints; /* 0 = rigid body; 3 = hexacopter + 3-link arm */
+  int32_t n_joints; /* 0 = rigid body; 1..3 = hexacopter + n-link arm (n < 3: the first n joints / links of the arrays below; same kernels,
+                       the caller's dimensions: 4 + n actions, 20 + 2 n + 3 observations, 2 n joint state fields; amenv_step only) */
   double mass;      /* kg  (params.py:10) */
   double g;         /* m/s^2 (params.py:11) */
   double inertia[9];     /* body inertia I (params.py:12-14) */
@@ -325,16 +328,20 @@ int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_
 /* Closed-loop rollout in ONE launch (SB3 collect_rollouts, v2/rl_train.py:38-56, for n_steps steps): per step
  *   obs_t -> actor / critic MLPs ([128, 64, 64] tanh; bf16 matrix cores, fp32 accumulate) -> a_t = mean + exp(log_std) z  (Philox keyed
  *   by (seed, global env id, draw0 + t) as amenv_gaussian_act) -> clip to the action box -> env step (as amenv_step, auto-reset included).
- * State, per-lane constants and the policy weights stay in registers between steps.  Built for the fp32 6-rotor vehicle with the z,x,x
- * arm (obs_dim 29, act_dim 7); other configurations return AMENV_ERR_INVALID.  The env part is the arithmetic of the kernel amenv_step
+ * State, per-lane constants and the policy weights stay in registers between steps.  Built for fp32 vehicles on the single-waypoint v2 task:
+ * the rigid vehicles with 4 or 6 rotors -- the reference's quadrotor (obs_dim 20, act_dim 4; default workgroup size; the env part is the
+ * lane-quad step, 4 lanes per env: replaying the recorded clipped actions through amenv_step on a handle created with AMENV_KERNEL_TEAM
+ * reproduces every row bit for bit; the first layer runs on two-part bf16 inputs and weights, which holds the action within 3e-2 of the
+ * fp32 policy's on the reference checkpoint) -- and the 6-rotor vehicle with the z,x,x 3-joint arm (obs_dim 29, act_dim 7); other
+ * configurations return AMENV_ERR_INVALID.  For the arm vehicle the env part is the arithmetic of the kernel amenv_step
  * runs for this env (16 lanes per env where that is the lane-team kernel, else one lane per env with the arithmetic of the LANE / HELPER step
  * kernels: replaying the recorded clipped actions through amenv_step on such a handle reproduces every row bit for bit; a handle whose
  * amenv_step runs the STAGED kernel agrees to rounding); both forms draw the same noise.  An opt-in ROLLOUT mode: bf16
  * rounding perturbs the action means by ~1e-2 of their scale; log-probs are those of the samples under the means actually used.
  *   flat_params  fp32 policy parameters in SB3 state-dict order (see amenv_policy_forward)
- *   obs          [n_steps + 1, N, 29] f32: row 0 <- observation at entry, row t + 1 <- after step t (post-reset for done envs)
- *   actions      [n_steps, N, 7] f32 raw (unclipped) samples;  logp, values, rewards [n_steps, N] f32;  dones [n_steps, N] u8
- *   info_bits    [n_steps, N] u32 or NULL;  terminal_obs [n_steps, N, 29] f32 or NULL (rows written only where dones != 0) */
+ *   obs          [n_steps + 1, N, obs_dim] f32: row 0 <- observation at entry, row t + 1 <- after step t (post-reset for done envs)
+ *   actions      [n_steps, N, act_dim] f32 raw (unclipped) samples;  logp, values, rewards [n_steps, N] f32;  dones [n_steps, N] u8
+ *   info_bits    [n_steps, N] u32 or NULL;  terminal_obs [n_steps, N, obs_dim] f32 or NULL (rows written only where dones != 0) */
 int amenv_rollout_policy(amenv* env, int32_t n_steps, const float* flat_params, uint64_t seed, uint32_t draw0, float* obs, float* actions,
                          float* logp, float* values, float* rewards, uint8_t* dones, uint32_t* info_bits, float* terminal_obs, void* stream);
 

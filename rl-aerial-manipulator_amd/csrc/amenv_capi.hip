@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -62,7 +63,7 @@ struct amenv {
 };
 
 static thread_local std::string g_create_err;
-constexpr int kTeamAutoMax = 8192;    // AUTO: lane-team arm kernel up to this batch (see amenv_create)
+constexpr int kTeamAutoMax = 6144;    // AUTO: lane-team arm kernel up to this batch (see amenv_create)
 constexpr int kArmkAutoMax = 32768;   // AUTO: stage-wave arm kernel up to this batch (see amenv_create)
 
 namespace {
@@ -482,11 +483,20 @@ template <int D, int A>
 hipError_t launch_mlp_step(const float* Pm, const float* WT, const float* obs, const float* actions, const float* old_logp, const float* adv, const float* ret,
                            const int64_t* index, int64_t n,
                            float clip, float vf, int normalize, const double* adv_part, int adv_blocks, float* part, int blocks, hipStream_t s) {
-  static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per kernel
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_fused_kernel<D, A>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMlpLds));
+  // > 64 KB of dynamic LDS needs the attribute on the device the launch goes to (the PPO entry points run on the CURRENT device): kept per
+  // device, under a lock -- a process that drives several GPUs would otherwise launch without it on the second one
+  {
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_fused_kernel<D, A>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMlpLds));
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
   }
   hipLaunchKernelGGL((ppo_mlp_fused_kernel<D, A>), dim3(blocks, 2), dim3(256), kMlpLds, s, Pm, WT, obs, actions, old_logp, adv, ret, index, n, clip, vf, normalize, adv_part,
                      adv_blocks, part);
@@ -652,7 +662,9 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // 4.9 vs 7.5 us at 2048 envs, 5.1 vs 7.6 at 4096, 7.5 vs 7.7 at 6144, 11.4 vs 7.8 at 8192 (a team workgroup is a main wave + an
   // episode-end helper wave: above 4096 envs the SIMDs hold more than two waves) -> AUTO up to 6144 envs with the body-parallel RK4.  With the
   // stage-parallel RK4 (tools/gpu_cross2.sh; against the stage-wave kernel): 4.69 vs 6.91 us at 4096 envs, 6.39 vs 6.96 at 5120, 6.64 vs 6.96 at 6144,
-  // 6.71 vs 7.01 at 7168, 6.81 vs 7.07 at 8192 (two main waves per SIMD), 10.3 vs 7.2 at 10240 -> AUTO up to 8192 envs
+  // 6.71 vs 7.01 at 7168, 6.81 vs 7.07 at 8192 (two main waves per SIMD), 10.3 vs 7.2 at 10240 -> AUTO up to 8192 envs.  Round 3 (the rewritten kernel
+  // keeps its per-lane constants and all loads in flight in registers: 155 VGPRs = three wavefronts per SIMD, profiles/r03/crossover_team_vs_stage_wave.txt):
+  // 4.51 vs 6.93 us at 4096 envs, 5.47 vs 6.94 at 5120, 5.96 vs 6.98 at 6144, 7.04 vs 6.99 at 7168, 8.06 vs 7.04 at 8192 -> AUTO up to 6144 envs
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes)
     e->team = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= kTeamAutoMax : want == AMENV_KERNEL_TEAM;
   // fp64 logic-gate build of the SAME kernel (DPP on register pairs): opt-in only, amenv_step only

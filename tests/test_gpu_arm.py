@@ -425,7 +425,7 @@ def test_closed_loop_policy_rollout_kernel(n, kernel):
             m.weight.mul_(30.0)
     env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel=kernel, max_episode_steps=60)
     ref = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=4, kernel="lane" if "armk" in env.kernel_name else kernel, max_episode_steps=60)
-    assert ("team" in env.kernel_name) == (kernel == "team" or (kernel == "auto" and n <= 8192)) and ("armk" in env.kernel_name) == (kernel == "auto" and n > 8192)
+    assert ("team" in env.kernel_name) == (kernel == "team" or (kernel == "auto" and n <= 6144)) and ("armk" in env.kernel_name) == (kernel == "auto" and n > 6144)
     o0 = env.reset().clone(); ref.reset()
     dev = env.device
     obs = torch.zeros(T + 1, n, 29, device=dev); acts = torch.zeros(T, n, 7, device=dev)

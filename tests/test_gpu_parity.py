@@ -357,7 +357,7 @@ def test_full_size_properties(amd, n, vehicle):
     runs = []
     for rep in range(2):
         env = amd.GpuWaypointEnv(n, seed=9, vehicle=vehicle, max_episode_steps=40)
-        assert ("team" in env.kernel_name) == (vehicle == "hexa_arm" and n <= 8192) and ("armk" in env.kernel_name) == (vehicle == "hexa_arm" and 8192 < n <= 32768)
+        assert ("team" in env.kernel_name) == (vehicle == "hexa_arm" and n <= 6144) and ("armk" in env.kernel_name) == (vehicle == "hexa_arm" and 6144 < n <= 32768)
         assert ("arm2w" in env.kernel_name) == (vehicle == "hexa_arm" and 32768 < n <= 65536)
         assert ("_pw" in env.kernel_name) == (vehicle != "hexa_arm" and n <= 32768)
         env.reset()

@@ -2,7 +2,7 @@
 set -o pipefail
 R=$PWD; O=$R/gpurun_out/team; mkdir -p $O; export TMPDIR=/tmp
 python -m pytest tests/test_gpu_arm.py -m gpu -x -q -p no:cacheprovider -k "policy_rollout" > $O/pytest_team.log 2>&1; echo "pytest exit $?"; grep -E "^E|passed|failed" $O/pytest_team.log | head -20
-for OCC in 1 2; do AMENV_POLICY_OCC=$OCC python - <<'PY'
+for OCC in auto; do python - <<'PY'
 import torch, os
 import rl_aerial_manipulator_amd as amd
 for n in (4096, 8192, 32768):
@@ -21,6 +21,6 @@ for n in (4096, 8192, 32768):
     for _ in range(8): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (8 * T)
-    print(f"OCC={os.environ['AMENV_POLICY_OCC']} closed-loop policy rollout n={n}: {us:.3f} us/step  {n / us * 1e6:.4g} env-steps/s")
+    print(f"closed-loop policy rollout n={n}: {us:.3f} us/step  {n / us * 1e6:.4g} env-steps/s")
 PY
 done
