@@ -120,7 +120,7 @@ typedef struct amenv_vehicle {
 /* Task constants that the reference keeps as literals in rl_env_scaledObs.py. */
 typedef struct amenv_task {
   int32_t variant;           /* AMENV_TASK_* */
-  int32_t num_waypoints;     /* K; reference hard-codes 1 (rl_env_scaledObs.py:47) */
+  int32_t num_waypoints;     /* K; reference hard-codes 1 (rl_env_scaledObs.py:47); arm vehicles: 1 on every kernel, 2..4 on the LANE kernel */
   int32_t max_episode_steps; /* 2000 (rl_env_scaledObs.py:56) */
   int32_t counter_limit;     /* 500  (rl_env_scaledObs.py:59) */
   int32_t rk4_substeps;      /* RK4 sub-steps per control step; 1 */

@@ -311,8 +311,8 @@ const char* validate(const amenv_config* c) {
   if (c->dtype != AMENV_F32 && c->dtype != AMENV_F64) return "dtype must be AMENV_F32 or AMENV_F64";
   if (c->vehicle.n_rotors < 1 || c->vehicle.n_rotors > AMENV_MAX_ROTORS) return "n_rotors out of range";
   if (c->vehicle.n_joints < 0 || c->vehicle.n_joints > AMENV_MAX_JOINTS) return "n_joints must be 0..3";
-  if (c->vehicle.n_joints > 0 && (c->vehicle.n_rotors != 6 || c->task.num_waypoints != 1 || is_v1(c)))
-    return "arm vehicles are built for the 6-rotor airframe, the v2 task and 1 waypoint (BASELINE config 3)";
+  if (c->vehicle.n_joints > 0 && (c->vehicle.n_rotors != 6 || is_v1(c)))
+    return "arm vehicles are built for the 6-rotor airframe and the v2 task (BASELINE config 3; 1 waypoint on every kernel, 2..4 on the lane kernel)";
   if (c->task.variant != AMENV_TASK_V2_SCALED20 && !is_v1(c)) return "unknown task variant";
   if (is_v1(c) && c->task.num_waypoints > 2) return "v1 tasks draw 1..2 waypoints per episode: num_waypoints (storage bound) must be 1 or 2";
   if (c->task.num_waypoints < 1 || c->task.num_waypoints > AMENV_MAX_WAYPOINTS) return "num_waypoints out of range";
@@ -434,7 +434,10 @@ hipError_t dispatch_k(const amenv& e, const StepIO& io, int T_steps, hipStream_t
 template <typename T>
 hipError_t dispatch_step(const amenv& e, const StepIO& io, int T_steps, hipStream_t s, bool timed = false) {
   const int nr = e.cfg.vehicle.n_rotors;
-  if (e.cfg.vehicle.n_joints == 3) return launch_step<T, 6, 1, VAR_V2, 3>(e, io, T_steps, s, timed);   // BASELINE config 3
+  if (e.cfg.vehicle.n_joints == 3) {
+    if (e.cfg.task.num_waypoints == 1) return launch_step<T, 6, 1, VAR_V2, 3>(e, io, T_steps, s, timed);   // BASELINE config 3
+    return launch_step<T, 6, AMENV_MAX_WAYPOINTS, VAR_V2, 3>(e, io, T_steps, s, timed);                    // arm + 2..4 waypoints: the lane kernel
+  }
   if (nr == 4) return dispatch_k<T, 4>(e, io, T_steps, s, timed);
   if (nr == 6) return dispatch_k<T, 6>(e, io, T_steps, s, timed);
   return dispatch_k<T, AMENV_MAX_ROTORS>(e, io, T_steps, s, timed);
@@ -649,7 +652,7 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   const int want = cfg->step_kernel;
   if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32) {
     const ArmParams<float> ap = make_arm<float>(*e);
-    e->arm2w = !ap.generic_axes && (want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 65536 : want == AMENV_KERNEL_HELPER);
+    e->arm2w = !ap.generic_axes && cfg->task.num_waypoints == 1 && (want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 65536 : want == AMENV_KERNEL_HELPER);
   }
   if (cfg->vehicle.n_joints == 0 && cfg->block_size == 0)
     e->pwave = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= 32768 : (want == AMENV_KERNEL_HELPER && cfg->num_envs <= 64 * kStatsReplicas);
@@ -665,10 +668,11 @@ int amenv_create(const amenv_config* cfg, int device, amenv** out) {
   // 6.71 vs 7.01 at 7168, 6.81 vs 7.07 at 8192 (two main waves per SIMD), 10.3 vs 7.2 at 10240 -> AUTO up to 8192 envs.  Round 3 (the rewritten kernel
   // keeps its per-lane constants and all loads in flight in registers: 155 VGPRs = three wavefronts per SIMD, profiles/r03/crossover_team_vs_stage_wave.txt):
   // 4.51 vs 6.93 us at 4096 envs, 5.47 vs 6.94 at 5120, 5.96 vs 6.98 at 6144, 7.04 vs 6.99 at 7168, 8.06 vs 7.04 at 8192 -> AUTO up to 6144 envs
-  if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes)
+  if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F32 && cfg->vehicle.n_rotors == 6 && !make_arm<float>(*e).generic_axes && cfg->task.num_waypoints == 1)
     e->team = want == AMENV_KERNEL_AUTO ? cfg->num_envs <= kTeamAutoMax : want == AMENV_KERNEL_TEAM;
   // fp64 logic-gate build of the SAME kernel (DPP on register pairs): opt-in only, amenv_step only
-  if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F64 && cfg->vehicle.n_rotors == 6 && !make_arm<double>(*e).generic_axes && want == AMENV_KERNEL_TEAM)
+  if (cfg->vehicle.n_joints == 3 && cfg->dtype == AMENV_F64 && cfg->vehicle.n_rotors == 6 && !make_arm<double>(*e).generic_axes && cfg->task.num_waypoints == 1 &&
+      want == AMENV_KERNEL_TEAM)
     e->team = true;
   // lane-quad kernel (4 lanes per env) for the rigid vehicles: fp32, 4 or 6 rotors, single-waypoint v2 task, default workgroup size
   const bool quad_ok = cfg->vehicle.n_joints == 0 && cfg->dtype == AMENV_F32 && (cfg->vehicle.n_rotors == 4 || cfg->vehicle.n_rotors == 6) && !is_v1(cfg) &&

@@ -84,8 +84,8 @@ __device__ __forceinline__ void load_env(int K, const char* tile_c, int lane, En
   }
 #pragma unroll
   for (int k = 0; k < AMENV_MAX_JOINTS; k++) { e.th[k] = T(0); e.thd[k] = T(0); }
-  if constexpr (NJ > 0) {          // joint angles, joint rates (NJ > 0 is only instantiated with KW = K)
-    const Vec4<T> a = *gptr<T>(tile, lane, 4 + KW), r = *gptr<T>(tile, lane, 5 + KW);
+  if constexpr (NJ > 0) {          // joint angles, joint rates: the two groups behind the K waypoint groups
+    const Vec4<T> a = *gptr<T>(tile, lane, 4 + K), r = *gptr<T>(tile, lane, 5 + K);
     e.th[0] = a.a; e.th[1] = a.b; e.th[2] = a.c;
     e.thd[0] = r.a; e.thd[1] = r.b; e.thd[2] = r.c;
   }
@@ -96,14 +96,14 @@ __device__ __forceinline__ void load_env(int K, const char* tile_c, int lane, En
 // per-step store: groups 0..3 + the int4 (final_yaw and episode are rewritten with their unchanged values); with an arm the two
 // joint groups as well (the waypoint group is not rewritten)
 template <typename T, int KW, int NJ = 0>
-__device__ __forceinline__ void store_env_step(char* tile, int lane, const Env<T, KW>& e) {
+__device__ __forceinline__ void store_env_step(char* tile, int lane, const Env<T, KW>& e, int K = KW) {   // K: waypoint groups of the configuration (arm: the joint groups sit behind them)
   *gptr<T>(tile, lane, 0) = Vec4<T>{e.px, e.py, e.pz, e.final_yaw};
   *gptr<T>(tile, lane, 1) = Vec4<T>{e.vx, e.vy, e.vz, e.last_distance};
   *gptr<T>(tile, lane, 2) = Vec4<T>{e.qw, e.qx, e.qy, e.qz};
   *gptr<T>(tile, lane, 3) = Vec4<T>{e.wx, e.wy, e.wz, e.ep_return};
   if constexpr (NJ > 0) {
-    *gptr<T>(tile, lane, 4 + KW) = Vec4<T>{e.th[0], e.th[1], e.th[2], T(0)};
-    *gptr<T>(tile, lane, 5 + KW) = Vec4<T>{e.thd[0], e.thd[1], e.thd[2], T(0)};
+    *gptr<T>(tile, lane, 4 + K) = Vec4<T>{e.th[0], e.th[1], e.th[2], T(0)};
+    *gptr<T>(tile, lane, 5 + K) = Vec4<T>{e.thd[0], e.thd[1], e.thd[2], T(0)};
   }
   *iptr4(tile, lane) = make_int4(e.step, e.counter, e.flags, e.episode);
 }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) AMENV_STEP_WAVES_ATTR void step_kernel(void* _
   const bool is_done = active && (bits & (AMENV_INFO_TERMINATED | AMENV_INFO_TRUNCATED)) != 0;
   AMENV_STAMP(3);          // dynamics + task + obs computed
   accumulate_stats(io.stats, int((blockIdx.x * blockDim.x + threadIdx.x) >> 6), bits, is_done, ep_len, ep_ret);
-  store_env_step<T, KW, NJ>(tile, lane, e);
+  store_env_step<T, KW, NJ>(tile, lane, e, K);
   if (was_reset) store_env_episode<T, KW>(K, tile, lane, e);
   if (active) {
     reinterpret_cast<T*>(io.reward)[i] = reward;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(void* __restrict__ blob, u
       __syncthreads();
     }
   }
-  store_env_step<T, KW, NJ>(tile, lane, e);
+  store_env_step<T, KW, NJ>(tile, lane, e, K);
   if (any_reset) store_env_episode<T, KW>(K, tile, lane, e);
 }
 

@@ -321,11 +321,8 @@ constexpr uint32_t kOob = 0xFFFFFFFFu;
 // step's travel of the crash / bounds thresholds).  A row that ends without having been announced (no such case is known) is reset by the
 // main wave itself, so the test only decides who does the work, never the result.  The totals replica is read only when an episode ended.
 // The first 8 dwords of the arguments are what the first loads need; the tile size is a constant of this kernel (one waypoint group, two joint groups).
-#ifndef AMENV_TEAM_STEP_ATTR
-#define AMENV_TEAM_STEP_ATTR
-#endif
 template <typename X, int NROT>
-__global__ __launch_bounds__(128) AMENV_TEAM_STEP_ATTR void step_kernel_team(void* __restrict__ blob, int32_t n_envs, int32_t n_blocks, const float* __restrict__ actions,
+__global__ __launch_bounds__(128) void step_kernel_team(void* __restrict__ blob, int32_t n_envs, int32_t n_blocks, const float* __restrict__ actions,
                                                         const void* __restrict__ lane_consts, float* __restrict__ obs, X* __restrict__ reward_out,
                                                         uint8_t* __restrict__ done, uint32_t* __restrict__ info, const StepTail tl, const ColdParams C) {
   constexpr uint32_t tile_bytes = kIntBytes + 7u * 64u * 4u * uint32_t(sizeof(X));
@@ -384,12 +381,13 @@ __global__ __launch_bounds__(128) AMENV_TEAM_STEP_ATTR void step_kernel_team(voi
     const X reach = fma_(dtc, abs_(E.y.V), abs_(E.y.P)) + slack;              // lanes 0..2 (lane 3 carries the per-env scalars: excluded below)
     const bool lane_may = (L.cc < 3 && !(reach < X(5.7735))) || (L.cc == 2 && !(E.y.P - dtc * abs_(E.y.V) - slack > X(0.1)));
     const unsigned long long mm = __ballot(lane_may);
-    const bool may = ((mm >> (L.lane & 48)) & 0xFFFFull) != 0ull || E.step >= P.max_steps || ((E.flags & AMENV_FLAGBIT_FWR) && E.counter >= P.counter_limit) ||
-                     (P.flags & AMENV_FLAG_NAN_GUARD);
 #ifdef AMENV_TEAM_DIAG_NOPREDICT   // diagnostic build: the helper never prepares a reset (the main wave computes it inline): timing only
-    const bool may_ = may; (void)may_;
-#define may false
+    constexpr bool kPredict = false;
+#else
+    constexpr bool kPredict = true;
 #endif
+    const bool may = kPredict && (((mm >> (L.lane & 48)) & 0xFFFFull) != 0ull || E.step >= P.max_steps || ((E.flags & AMENV_FLAGBIT_FWR) && E.counter >= P.counter_limit) ||
+                                  (P.flags & AMENV_FLAG_NAN_GUARD));
     if (L.lead) have[row] = may ? 1u : 0u;
     unsigned long long* totals = tl.stats + size_t(blockIdx.x & (kStatsReplicas - 1)) * kStatsStride;
     unsigned long long mine = 0ull;
@@ -403,9 +401,6 @@ __global__ __launch_bounds__(128) AMENV_TEAM_STEP_ATTR void step_kernel_team(voi
         rst[3][L.lane] = R.vA; rst[4][L.lane] = R.vB; rst[5][L.lane] = R.vC;
       }
     }
-#ifdef AMENV_TEAM_DIAG_NOPREDICT
-#undef may
-#endif
     __syncthreads();
 #ifdef AMENV_TEAM_DIAG_NOPOST   // diagnostic build: the helper leaves after the barrier (no Monitor service: timing only)
     return;

@@ -628,3 +628,56 @@ def test_n_link_arm_with_fewer_joints(nj, dtype, kernel, tol):
     with pytest.raises(amd.AmenvError, match="1 or 2 joints|logic gate"):
         env.rollout(torch.zeros(2, n, 4 + nj, device="cuda"))
     env.close()
+
+
+@pytest.mark.parametrize("K,dtype,tol", [(3, "f64", 1e-12), (2, "f32", 3e-6), (4, "f32", 3e-6)])
+def test_arm_with_several_waypoints(K, dtype, tol):
+    """The arm vehicle on the multi-waypoint v2 task (2..4 waypoints per episode; the lane kernel: the joint groups sit behind K waypoint groups):
+    teacher-forced per step against the oracle with waypoint switching (+100, next-waypoint entries of the observation), resets bit-exact; the
+    one-waypoint kernel families refuse the combination."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n = 600
+    rng = np.random.RandomState(K)
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=12, dtype=dtype, num_waypoints=K, max_episode_steps=120)
+    assert "step_kernel<" in env.kernel_name and f"KW={amd._lib.MAX_WAYPOINTS}" in env.kernel_name and env.n_float_fields == 16 + 3 * K + 6
+    cfg = arm_cfg()
+    multi = O.reference_quad_config(n, seed=12, num_waypoints=K)
+    C.memmove(C.byref(multi.vehicle), C.byref(cfg.vehicle), C.sizeof(O.Vehicle))
+    multi.task.ee_task = cfg.task.ee_task; multi.task.max_episode_steps = 120
+    orc = O.OracleEnv(multi)
+    obs0 = env.reset().cpu().numpy(); oobs0 = orc.reset()
+    f, i = gpu_state(env)
+    assert np.array_equal(f, orc.fstate) and np.array_equal(i, orc.istate)
+    np.testing.assert_allclose(obs0, oobs0, rtol=OBS_ULP, atol=1.5e-7)
+    # park a third of the envs ON their current waypoint (tool point = waypoint), so that the switch to the next one is exercised at once
+    ee = orc.ee_position()
+    park = np.arange(n) % 3 == 0
+    f[0:3, park] += (f[16:19, park] - ee[park].T)
+    j0 = 16 + 3 * K
+    f[j0:j0 + 3] = rng.uniform(-0.5, 0.5, (3, n)); f[j0 + 3:j0 + 6] = rng.normal(0, 0.5, (3, n))
+    f[0:3, ~park] += rng.normal(0, 0.05, (3, int((~park).sum())))
+    env.set_state(f if dtype == "f64" else f.astype(np.float32), i)
+    worst = 0.0; worst_obs = 0.0; flips = 0; switched = 0; dones = 0
+    for t in range(140):
+        a = rand_actions(rng, n)
+        a[::9, 0] = 0.0
+        g, o = both_step(env, orc, a)
+        f2, i2 = gpu_state(env)
+        bad = np.nonzero((g["info"] & 127) != (o["info"] & 127))[0]
+        flips += len(bad)
+        ok = np.ones(n, bool); ok[bad] = False
+        nd = ok & (o["done"] == 0)
+        rows = np.r_[0:15, 16:16 + 3 * K + 6]
+        if nd.any():
+            worst = max(worst, rel_err(f2[rows][:, nd], orc.fstate[rows][:, nd]).max())
+        worst_obs = max(worst_obs, rel_err(g["obs"][ok], o["obs"][ok]).max())
+        switched += int(((i2[O.I_FLAGS] & 15) > 0)[ok].sum())
+        dn = ok & (o["done"] != 0)
+        dones += int(dn.sum())
+        assert np.array_equal(f2[:, dn], orc.fstate[:, dn]) and np.array_equal(i2[:, ok], orc.istate[:, ok])
+    assert worst < tol and worst_obs < max(tol, 1.3e-7) and flips <= 3 and switched > 1000 and dones > 50, (worst, worst_obs, flips, switched, dones)
+    for kernel in ("team", "staged", "helper"):
+        with pytest.raises(amd.AmenvError):
+            amd.GpuWaypointEnv(64, vehicle="hexa_arm", num_waypoints=K, kernel=kernel)
+    env.close()
