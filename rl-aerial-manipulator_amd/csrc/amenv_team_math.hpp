@@ -2,7 +2,7 @@
 //
 //   float   the product: one env = one DPP row of 16 lanes, cross-lane operands through DPP modifiers (amenv_team.hpp)
 //   double  the fp64 logic-gate build of the SAME kernel on the GPU (DPP on register pairs): every selector, row sum and stage hand-over of the
-//           product's plumbing is then held to <= 1e-12 against the fp64 oracle (tests/test_gpu_team.py)
+//           product's plumbing is then held to <= 1e-12 against the fp64 oracle (tests/test_gpu_arm.py)
 //   HV      a host emulation (16 explicit lanes, fp64): tests/emu/team_emu.cpp compiles this header with g++ so that the formulation is
 //           checked against the oracle in the CPU suite, without a GPU (tests/test_team_emu_cpu.py).  Test infrastructure only.
 //

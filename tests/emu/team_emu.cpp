@@ -4,7 +4,7 @@
 // row_shr) are permutations of that array with the hardware's semantics.  The SAME source as the HIP kernels, so a wrong selector, a
 // mis-associated row sum or a wrong hand-over direction in the formulation shows up against the fp64 oracle in the CPU suite
 // (tests/test_team_emu_cpu.py).  Nothing in the product loads this library; the HIP kernels themselves are checked on the GPU
-// (tests/test_gpu_team.py: fp64 build <= 1e-12, fp32 build to rounding).
+// (tests/test_gpu_arm.py: fp64 build <= 1e-12, fp32 build to rounding).
 #include <cmath>
 #include <cstdint>
 #include <cstring>

@@ -83,9 +83,9 @@ def test_each_quad_holds_its_own_rk4_stage(emu):
     assert worst < 1e-12, worst
 
 
-def test_rigid_limit_and_heavy_arm(emu):
-    """Parameter sweeps the default vehicle does not reach: massless links (== rigid hexacopter dynamics of the base) and links ten times
-    heavier with off-diagonal inertias everywhere (every term of the aggregates carries weight)."""
+def test_heavy_arm_with_full_inertias(emu):
+    """A parameter set the default vehicle does not reach: links ten times heavier, every link inertia a full (rotated) tensor, CoMs off the joint
+    axes -- every term of the aggregates carries weight, including link 1's closed form with off-diagonal inertia entries."""
     rng = np.random.RandomState(11)
     s, a = random_states(rng, 256)
     cfg = arm_cfg()
