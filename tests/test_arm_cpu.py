@@ -319,3 +319,34 @@ def test_staged_form_of_the_arm_dynamics_is_the_same_right_hand_side():
         worst = max(worst, np.abs(vd - d[3:6]).max() / max(1.0, np.abs(d[3:6]).max()), np.abs(wd - d[10:13]).max() / max(1.0, np.abs(d[10:13]).max()),
                     np.abs(thdd - d[16:19]).max())
     assert worst < 1e-12, worst
+
+
+def test_phantom_links_are_exact_zeros():
+    """The n-link adapter of the C ABI (n_joints = 1, 2: amenv_capi.hip pad_arm_config) runs the 3-joint kernels with PHANTOM links behind the real
+    ones -- zero mass / inertia / CoM / joint offset, x axes, joint limits 0.  On the oracle: the padded 3-joint vehicle and the native shorter chain
+    give the same step (the phantom terms are exact zeros, their rotations the identity) and the same tool point."""
+    rng = np.random.RandomState(4)
+    lm = [0.082, 0.054, 0.220]
+    for nj in (1, 2):
+        mass = 3.2121 - sum(lm[nj:])
+        short = arm_cfg(n_joints=nj, mass=mass)
+        padded = arm_cfg(mass=mass)
+        v = padded.vehicle
+        for k in range(nj, 3):
+            v.link_mass[k] = 0.0
+            for j in range(3):
+                v.joint_origin[3 * k + j] = 0.0; v.link_com[3 * k + j] = 0.0; v.joint_axis[3 * k + j] = 1.0 if j == 0 else 0.0
+            for j in range(9):
+                v.link_inertia[9 * k + j] = 0.0
+            v.joint_limit[2 * k] = v.joint_limit[2 * k + 1] = 0.0
+        for _ in range(50):
+            s = np.zeros(19)
+            s[:6] = rng.normal(size=6); q = rng.normal(size=4); s[6:10] = q / np.linalg.norm(q); s[10:13] = rng.normal(size=3) * 2
+            s[13:13 + nj] = rng.uniform(-1.5, 1.5, nj); s[16:16 + nj] = rng.normal(size=nj) * 2
+            a = rng.uniform(-1, 1, 7).astype(np.float32); a[0] = rng.uniform(0, 2)
+            a_short = a[:4 + nj].copy()
+            a[4 + nj:] = rng.uniform(-1, 1, 3 - nj)          # whatever the padded action columns hold: limits 0 -> command 0
+            s1, _ = O.arm_dynamics_step(short, s, a_short)
+            s2, _ = O.arm_dynamics_step(padded, s, a)
+            assert np.abs(s1 - s2).max() < 1e-14 and np.all(s2[13 + nj:16] == 0) and np.all(s2[16 + nj:19] == 0)
+            assert np.abs(O.ee_position(short, s1) - O.ee_position(padded, s2)).max() < 1e-15
