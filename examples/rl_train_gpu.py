@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--save", default="waypoint_controller_gpu")         # rl_train.py:57
     ap.add_argument("--vehicle", default="quad")
     ap.add_argument("--moment-scale", type=float, default=None, help="N m per unit moment action (amenv_vehicle.moment_scale; the reference quadrotor: 0.1)")
+    ap.add_argument("--fused-rollout", action="store_true", help="collect every rollout as ONE launch (amenv_rollout_policy: the policy on bf16 matrix cores inside the env loop; "
+                                                                 "log-probs / values of the buffer re-evaluated in fp32); quadrotor, hexacopter, hexacopter + arm")
+    ap.add_argument("--log-json", default=None, help="write the learning curve (one record per iteration) and the final evaluation to this file")
     ap.add_argument("--warm-start-pid", type=int, default=None, metavar="DAGGER_ROUNDS",
                     help="initialise the actor by behaviour cloning of the PID + minimum-snap baseline (amd.clone_pid_policy; 0 = plain cloning, k = k DAgger rounds). "
                          "Needed for the hexacopter vehicles: from SB3's default initialisation PPO does not leave the free-fall plateau there (profiles/r03/ppo_hexa_sweep_*.json)")
@@ -45,7 +48,7 @@ def main():
         cfg.seed, cfg.env_id_offset = 0, sh.env_id_offset
     env = amd.GpuWaypointEnv(a.envs, device=local, vehicle=a.vehicle, seed=0, env_id_offset=sh.env_id_offset, config=cfg)
     model = amd.PPO(env, learning_rate=2e-4, n_steps=a.n_steps, batch_size=a.envs * a.n_steps // 128, n_epochs=12, gamma=0.995,
-                    gae_lambda=0.9, clip_range=0.2, ent_coef=1e-4 if a.resume else 5e-4, dist=dist)
+                    gae_lambda=0.9, clip_range=0.2, ent_coef=1e-4 if a.resume else 5e-4, dist=dist, fused_rollout=a.fused_rollout)
     if a.resume:
         model.load_policy(a.resume)
     elif a.warm_start_pid is not None:
@@ -55,12 +58,27 @@ def main():
                 dist.broadcast(p_.data, src=0)
         if sh.rank == 0:
             print(f"warm start: actor cloned from PidWaypointPolicy (mse {mse:.4f}, {a.warm_start_pid} DAgger rounds), log_std = -1", flush=True)
-    show = (lambda r: print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)) if sh.rank == 0 else None
-    model.learn(a.timesteps, log_fn=show)
+    curve = []
+
+    def show(r):
+        curve.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()})
+        print(curve[-1], flush=True)
+
+    import time
+    t0 = time.time()
+    model.learn(a.timesteps, log_fn=show if sh.rank == 0 else None)
+    seconds = time.time() - t0
     if sh.rank == 0:
         print("saved", model.save(a.save))
         mean_reward, std_reward = amd.evaluate_policy(model, env, n_eval_episodes=max(10, a.envs))      # rl_train.py:60-61
         print(f"Mean reward: {mean_reward} +/- {std_reward}")
+        if a.log_json:
+            import json
+            first90 = next((c["timesteps"] for c in curve if c["success_rate"] > 0.9), None)
+            with open(a.log_json, "w") as f:
+                json.dump({"command": " ".join(sys.argv), "learn_seconds": seconds, "timesteps": a.timesteps, "timesteps_to_90pct_success": first90,
+                           "final_success_rate_mean_of_last_10_iterations": sum(c["success_rate"] for c in curve[-10:]) / max(1, len(curve[-10:])),
+                           "evaluate_policy_mean_reward": mean_reward, "evaluate_policy_std_reward": std_reward, "curve_every_20th_iteration": curve[::20]}, f, indent=1)
     if dist is not None:
         dist.destroy_process_group()
 
