@@ -681,3 +681,45 @@ def test_arm_with_several_waypoints(K, dtype, tol):
         with pytest.raises(amd.AmenvError):
             amd.GpuWaypointEnv(64, vehicle="hexa_arm", num_waypoints=K, kernel=kernel)
     env.close()
+
+
+@pytest.mark.parametrize("kernel", ["team", "staged", "lane"])
+def test_arm_kernels_with_nan_guard_and_without_auto_reset(kernel):
+    """The configuration switches on the arm kernels (the lane-team kernel's helper wave decides per row whether to prepare a reset; with the NaN
+    guard it always does): (1) AMENV_FLAG_NAN_GUARD: a poisoned env ends with terminated | NONFINITE, reward -100, and is reset; the others
+    step exactly as without the flag; (2) auto-reset off: an env that ends is NOT reset (state keeps integrating, flags say done), Monitor
+    outputs and totals still count it."""
+    import torch
+    import rl_aerial_manipulator_amd as amd
+    n = 333
+    act = torch.tensor([[1.0, 0.02, -0.01, 0.0, 0.3, -0.2, 0.1]], device="cuda").repeat(n, 1)
+    plain = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, kernel=kernel)
+    guard = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, kernel=kernel, nan_guard=True)
+    plain.reset(); guard.reset()
+    for _ in range(3):
+        o1, r1, d1, i1 = plain.step(act); o2, r2, d2, i2 = guard.step(act)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(i1, i2)
+    f, i = guard.get_state()
+    f[3, 7] = float("nan"); f[1, 200] = float("inf")
+    guard.set_state(f, i)
+    o2, r2, d2, i2 = guard.step(act)
+    bits = i2.cpu().numpy().view(np.uint32)
+    assert (bits[[7, 200]] & O.INFO_NONFINITE).all() and (bits[[7, 200]] & O.INFO_WAS_RESET).all() and d2[7] == 1 and d2[200] == 1 and float(r2[7]) == -100.0
+    assert (np.delete(bits, [7, 200]) & O.INFO_NONFINITE == 0).all() and bool(torch.isfinite(o2).all())
+    f2, i2s = guard.get_state()
+    assert int(i2s[3, 7]) == 2 and int(i2s[0, 7]) == 0 and bool(torch.isfinite(f2).all())
+    plain.close(); guard.close()
+    # (2) no auto-reset: drop env 11 to the ground
+    env = amd.GpuWaypointEnv(n, vehicle="hexa_arm", seed=3, kernel=kernel, auto_reset=False)
+    env.reset(); env.stats(reset=True)
+    f, i = env.get_state()
+    f[2, 11] = 0.05; f[5, 11] = -1.0
+    env.set_state(f, i)
+    o, r, d, info = env.step(act)
+    bits = info.cpu().numpy().view(np.uint32)
+    assert d[11] == 1 and (bits[11] & O.INFO_CRASHED) and not (bits[11] & O.INFO_WAS_RESET) and int(d.sum()) == 1
+    f2, i2s = env.get_state()
+    assert int(i2s[3, 11]) == 1 and int(i2s[0, 11]) == 1 and float(f2[2, 11]) < 0.05          # same episode, one step on, still falling
+    st = env.stats()
+    assert st["episodes"] == 1 and st["crashed"] == 1 and int(env.ep_len[11]) == 1
+    env.close()
