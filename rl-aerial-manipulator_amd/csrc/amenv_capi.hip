@@ -476,14 +476,14 @@ __global__ void calibration_copy_kernel(const V* __restrict__ src, V* __restrict
 
 }  // namespace
 
-// workspace of amenv_ppo_mlp_step: advantage partials | k-major weight copies of both nets | per-workgroup gradient slabs of both nets
+// workspace of amenv_ppo_mlp_step: advantage partials | split-weight streams of both nets | per-workgroup gradient slabs of both nets
 namespace {
 constexpr size_t kMlpWsAdv = size_t(2) * kPpoMaxBlocks * sizeof(double);
-constexpr size_t kMlpWsWt = size_t(2) * kMlpWtPerNet * sizeof(float);
+constexpr size_t kMlpWsWt = size_t(2) * kMlpFragsPerNet * 1024;
 constexpr size_t kMlpWsPart = size_t(2) * kMlpMaxBlocks * kAccSize * sizeof(float);
-constexpr size_t kMlpLds = (size_t(kXposeRows) * kXs + 64) * sizeof(float);
+constexpr size_t kMlpLds = kMlpLdsBytes;
 template <int D, int A>
-hipError_t launch_mlp_step(const float* Pm, const float* WT, const float* obs, const float* actions, const float* old_logp, const float* adv, const float* ret,
+hipError_t launch_mlp_step(const float* Pm, const u32x4* WS, const float* obs, const float* actions, const float* old_logp, const float* adv, const float* ret,
                            const int64_t* index, int64_t n,
                            float clip, float vf, int normalize, const double* adv_part, int adv_blocks, float* part, int blocks, hipStream_t s) {
   // > 64 KB of dynamic LDS needs the attribute on the device the launch goes to (the PPO entry points run on the CURRENT device): kept per
@@ -501,7 +501,7 @@ hipError_t launch_mlp_step(const float* Pm, const float* WT, const float* obs, c
       if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((ppo_mlp_fused_kernel<D, A>), dim3(blocks, 2), dim3(256), kMlpLds, s, Pm, WT, obs, actions, old_logp, adv, ret, index, n, clip, vf, normalize, adv_part,
+  hipLaunchKernelGGL((ppo_mlp_fused_kernel<D, A>), dim3(blocks, 2), dim3(256), kMlpLds, s, Pm, WS, obs, actions, old_logp, adv, ret, index, n, clip, vf, normalize, adv_part,
                      adv_blocks, part);
   return hipGetLastError();
 }
@@ -1164,17 +1164,17 @@ int amenv_ppo_mlp_step(const float* flat_params, int32_t obs_dim, int32_t act_di
   hipStream_t s = (hipStream_t)stream;
   char* ws = static_cast<char*>(workspace);
   double* adv_part = reinterpret_cast<double*>(ws);
-  float* WT = reinterpret_cast<float*>(ws + kMlpWsAdv);
+  uint16_t* WS = reinterpret_cast<uint16_t*>(ws + kMlpWsAdv);
   float* part = reinterpret_cast<float*>(ws + kMlpWsAdv + kMlpWsWt);
   const int adv_blocks = int(std::min<int64_t>(kPpoMaxBlocks, (n + kPpoBlock - 1) / kPpoBlock));
   const int64_t ntiles = (n + 31) / 32;
   const int blocks = int(std::min<int64_t>(128, (ntiles + 3) / 4));   // 128 x 2 nets x 4 wavefronts = one wavefront per SIMD
-  hipLaunchKernelGGL(ppo_mlp_prologue_kernel, dim3(adv_blocks + (2 * kMlpWtPerNet + kPpoBlock - 1) / kPpoBlock), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part, index,
-                     adv_blocks, flat_params, (int)obs_dim, (int)act_dim, WT);
+  hipLaunchKernelGGL(ppo_mlp_prologue_kernel, dim3(adv_blocks + (2 * kMlpPackThreadsPerNet + kPpoBlock - 1) / kPpoBlock), dim3(kPpoBlock), 0, s, advantages, (int64_t)n, adv_part, index,
+                     adv_blocks, flat_params, (int)obs_dim, (int)act_dim, WS);
   hipError_t st;
-  if (obs_dim == 20 && act_dim == 4) st = launch_mlp_step<20, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
-  else if (obs_dim == 29 && act_dim == 7) st = launch_mlp_step<29, 7>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
-  else if (obs_dim == 17 && act_dim == 4) st = launch_mlp_step<17, 4>(flat_params, WT, obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  if (obs_dim == 20 && act_dim == 4) st = launch_mlp_step<20, 4>(flat_params, reinterpret_cast<const u32x4*>(WS), obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  else if (obs_dim == 29 && act_dim == 7) st = launch_mlp_step<29, 7>(flat_params, reinterpret_cast<const u32x4*>(WS), obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
+  else if (obs_dim == 17 && act_dim == 4) st = launch_mlp_step<17, 4>(flat_params, reinterpret_cast<const u32x4*>(WS), obs, actions, old_logp, advantages, returns, index, n, clip_range, vf_coef, normalize_advantage, adv_part, adv_blocks, part, blocks, s);
   else return AMENV_ERR_INVALID;
   if (st != hipSuccess) return AMENV_ERR_HIP;
   const int trunk = kH1 * obs_dim + kH1 + kH2 * kH1 + kH2 + kH3 * kH2 + kH3;

@@ -2,22 +2,30 @@
 // tanh, separate actor / critic trunks) as ONE kernel: forward of both MLPs, SB3's loss and its gradient, backward through both MLPs and
 // all weight / bias gradients.  PyTorch ran this as ~90 library launches per minibatch (~0.9 ms for 65,536 samples, ~15 TFLOP/s).
 //
-// Arithmetic: fp32 in, fp32 out on the matrix cores -- v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fp32 fma chain, so the result
-// differs from torch's fp32 modules only by summation order (test: <= 2e-5 of the largest gradient entry).
+// Arithmetic: fp32 in, fp32 out, on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 parts (x = hi + mid + lo,
+// 8 significant bits each, by truncation) and a product a b is formed from the six partial products of weight >= 2^-16
+// (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid) by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped ones are below
+// 2^-23 |a b| -- the size of one fp32 rounding.  Round 2 ran the same data flow on v_mfma_f32_32x32x2_f32: on gfx950 that instruction
+// issues at the vector FMA rate (157 TFLOP/s) and shares its issue slots with the wavefront's other VALU work (tools/micro/mfma_rate.hip);
+// six bf16 MFMAs cover K = 16 in 192 clocks where eight fp32 MFMAs took 512, and VALU instructions cost ~2 clocks each in their shadow
+// (tools/micro/mfma_bf16_rate.hip).  Against torch's fp32 modules the gradient differs by summation order only (test: <= 2e-5 of the
+// largest gradient entry, unchanged from the fp32-MFMA version).
 //
 // Data flow of one wavefront = one tile of 32 samples (blockIdx.y = net: 0 actor, 1 critic):
 //   * orientation D = W . X^T: M = 32 output neurons, N = the tile's 32 samples, K = inputs.  The accumulator tile of layer l (rows =
-//     neurons in the 16 registers, column = sample on the lane) IS the B operand of layer l + 1: k-step (tile t, register r) consumes,
-//     in lane half h, the neuron 32 t + (r & 3) + 8 (r >> 2) + 4 h -- exactly the row that register holds.  Activations never leave
-//     registers on the forward pass nor on the data-gradient pass (dH = W^T dZ has the same shape); tanh and tanh' are lane-local.
-//   * weights are the A operands, one coalesced 256-byte global load per MFMA (L2-resident: 66 KB per net): the forward reads the
-//     k-major copies W^T (made by mlp_transpose_kernel after every optimiser step), the data-gradient pass the row-major originals.
-//   * weight gradients contract over SAMPLES: the four wavefronts of a workgroup pool their tiles -- dZ and the layer inputs go through
-//     an LDS transpose ([neuron][128 samples + 1]: written lane = sample, read lane = neuron, both conflict-free) -- and every 32 x 32
-//     tile of every dW is OWNED by one wavefront, which accumulates it in registers over all samples the workgroup sees (64 k-steps per
-//     iteration).  No atomics: a first version added per-wavefront tiles into an LDS accumulator with ds_add_f32 and spent 76 % of its
-//     time there.  Bias gradients ride along as the running sum of the A fragments.  At the end a workgroup writes its tiles to a partial
-//     slab; mlp_grad_reduce_kernel sums the slabs in a fixed order into the flat gradient: the step is deterministic.
+//     neurons in the 16 registers, column = sample on the lane) IS the B operand of layer l + 1: the MFMA pairs element j of lane half g
+//     of A with element j of lane half g of B whatever k they stand for, so k-group q of input tile t is DEFINED as the rows registers
+//     8 q .. 8 q + 7 hold: k = 32 t + 16 q + (j & 3) + 8 (j >> 2) + 4 g.  Activations never leave registers on the forward pass nor on
+//     the data-gradient pass (dH = W^T dZ has the same shape); tanh, tanh' and the three-way split are lane-local.
+//   * weights are the A operands: mlp_pack_element (prologue launch, after every optimiser step) writes, per net, the split weights of
+//     the four forward and three data-gradient passes as a stream of 1-KB fragments in exactly the order the kernel consumes them
+//     (chunk = (output tile, input tile) x k-group x part; lane x 8 bf16 = one 16-byte load per lane), L2-resident (186 KB per net),
+//     fetched two chunks ahead of the MFMAs that use them.
+//   * weight gradients contract over SAMPLES: the four wavefronts of a workgroup pool their tiles -- the split dZ and layer inputs go
+//     through an LDS transpose (three bf16 planes [neuron][128 samples]: written lane = sample, read 8 consecutive samples per lane as
+//     one ds_read_b128) -- and every 32 x 32 tile of every dW is OWNED by one wavefront, which accumulates it in registers over all
+//     samples the workgroup sees.  No atomics.  Bias gradients ride along as v_dot2 sums of the A fragments.  At the end a workgroup
+//     writes its tiles to a partial slab; mlp_grad_reduce_kernel sums the slabs in a fixed order into the flat gradient: deterministic.
 //   * the loss part is SB3's (amenv_train.hpp ppo_loss_grad, same expressions), evaluated on the accumulator tile of the head: the 7
 //     action means of a sample sit in registers 0..3 of the two lane halves.
 #pragma once
@@ -29,16 +37,31 @@
 namespace amenv_dev {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kH1 = 128, kH2 = 64, kH3 = 64;
-// per net: W1^T [32][128] | W2^T [128][64] | W3^T [64][64] | W4^T [64][32] | W4 padded to 32 rows [32][64]  (zeros where a row / column does not exist)
-constexpr int kMlpWtPerNet = 32 * kH1 + kH1 * kH2 + kH2 * kH3 + kH3 * 32 + 32 * kH3;
 // per-workgroup gradient accumulator (floats): dW1 [128][33] (col 32 = bias) | dW2 [64][129] | dW3 [64][65] | dW4 [32][65] | stats [16]
 constexpr int kAccW1 = 0, kAccW2 = kAccW1 + kH1 * 33, kAccW3 = kAccW2 + kH2 * 129, kAccW4 = kAccW3 + kH3 * 65, kAccStats = kAccW4 + 32 * 65;
 constexpr int kAccSize = kAccStats + 16;
 constexpr int kXs = 129;                                                      // transpose row stride: 4 wavefronts x 32 samples + 1
 constexpr int kXposeRows = 192;                                               // largest layer: dZ2 (64 rows) + H1 (128 rows)
+constexpr int kMlpLdsBytes = (kXposeRows * kXs + 64) * 4;                     // + stats [4 wavefronts][16]
 constexpr int kMlpMaxBlocks = 256;
+
+// The split-weight stream of one net: passes in the order the kernel runs them; a pass = NT output tiles x KT input tiles chunks, a chunk =
+// NQ k-groups x 3 parts fragments of 64 lanes x 8 bf16 (1 KB).
+struct MlpPass { int nt, kt, nq; };
+__host__ __device__ constexpr MlpPass mlp_pass(int p) {
+  return p == 0 ? MlpPass{4, 1, 2} : p == 1 ? MlpPass{2, 4, 2} : p == 2 ? MlpPass{2, 2, 2} : p == 3 ? MlpPass{1, 2, 2}   // forward: layer 1 (32 -> 128), 2 (128 -> 64), 3 (64 -> 64), head (64 -> 32)
+       : p == 4 ? MlpPass{2, 1, 1} : p == 5 ? MlpPass{2, 2, 2} : MlpPass{4, 2, 2};                                       // data gradients: head (rows 0..15 of dY -> 64), layer 3 (64 -> 64), layer 2 (64 -> 128)
+}
+__host__ __device__ constexpr int mlp_pass_units(int p) { return mlp_pass(p).nt * mlp_pass(p).kt * mlp_pass(p).nq; }   // (chunk, k-group) units
+template <int P> struct MlpUnitBase { static constexpr int value = MlpUnitBase<P - 1>::value + mlp_pass_units(P - 1); };   // first unit of pass P
+template <> struct MlpUnitBase<0> { static constexpr int value = 0; };
+constexpr int kMlpUnitsPerNet = MlpUnitBase<6>::value + mlp_pass_units(6);   // 62
+constexpr int kMlpFragsPerNet = 3 * kMlpUnitsPerNet;                          // 186 fragments of 1 KB
+constexpr int kMlpPackThreadsPerNet = kMlpUnitsPerNet * 512;                  // one thread per (unit, lane, j): writes the three parts
 
 __host__ __device__ constexpr int mlp_rowmap(int r) { return (r & 3) + 8 * (r >> 2); }   // row of accumulator register r (+ 4 for the upper lane half)
 
@@ -47,6 +70,37 @@ __device__ __forceinline__ float tanh_acc(float x) {   // 1 - 2 / (exp(2x) + 1):
   const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return fma_(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
 }
+
+// x = hi + mid + lo exactly, each part 8 significant bits (bf16 by truncation; lo needs no masking: what is left has <= 8 bits)
+__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  lo = __float_as_uint(r1 - __uint_as_float(mid));
+}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t even, uint32_t odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }   // (odd & 0xffff0000) | (even >> 16)
+
+// the three bf16 parts of the 8 values of one k-group, packed as MFMA operands: p[part][d] = elements 2 d (low half), 2 d + 1 (high half)
+struct Bf3 { u32x4 p[3]; };
+__device__ __forceinline__ void split_pair(float v0, float v1, Bf3& s, int d) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split3(v0, h0, m0, l0); split3(v1, h1, m1, l1);
+  s.p[0][d] = pack_hi16(h0, h1); s.p[1][d] = pack_hi16(m0, m1); s.p[2][d] = pack_hi16(l0, l1);
+}
+template <int NQ = 2>
+__device__ __forceinline__ void split_tile(const f32x16& v, Bf3* s) {   // s[q]: registers 8 q .. 8 q + 7
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int d = 0; d < 4; d++) split_pair(v[8 * q + 2 * d], v[8 * q + 2 * d + 1], s[q], d);
+}
+
+// acc += A . B from the six partial products of weight >= 2^-16, smallest first
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__host__ __device__ constexpr int prod_a(int i) { return (0x001102 >> (4 * i)) & 15; }   // A parts 2 0 1 1 0 0
+__host__ __device__ constexpr int prod_b(int i) { return (0x010120 >> (4 * i)) & 15; }   // B parts 0 2 1 0 1 0
 
 // trunk / head parameter offsets inside the flat buffer (SB3 order, see amenv_team_policy.hpp PolLayout)
 struct MlpNet {
@@ -64,86 +118,112 @@ __device__ __forceinline__ MlpNet mlp_net(const float* Pm, int D, int A, int net
   return N;
 }
 
-// k-major copies of the four weight matrices of both nets (forward-pass A operands): one thread per element
-__device__ __forceinline__ void mlp_transpose_element(const float* __restrict__ Pm, int D, int A, float* __restrict__ WT, int tid) {
-  if (tid >= 2 * kMlpWtPerNet) return;
-  const int net = tid / kMlpWtPerNet, e = tid % kMlpWtPerNet;
+// One element of the split-weight stream: thread = (net, unit = (chunk, k-group) of a pass, lane, j).  Lane (m, g) of the A operand of
+// output tile `tile`, input tile `kt`, k-group q holds, in element j, the weight that multiplies input k = 32 kt + 16 q + (j & 3) +
+// 8 (j >> 2) + 4 g into output 32 tile + m: W[out][k] on the forward passes, W[k][out] (out = input neuron) on the data-gradient passes;
+// zero where the row / column does not exist.  The three parts go to fragments 3 unit + {0, 1, 2}.
+__device__ __forceinline__ void mlp_pack_element(const float* __restrict__ Pm, int D, int A, uint16_t* __restrict__ WS, int tid) {
+  if (tid >= 2 * kMlpPackThreadsPerNet) return;
+  const int net = tid / kMlpPackThreadsPerNet, e = tid % kMlpPackThreadsPerNet;
+  const int unit = e >> 9, lane = (e >> 3) & 63, j = e & 7, m = lane & 31, g = lane >> 5;
+  int pass = 0, ubase = 0;
+#define MLP_PASS_OF(P) if (unit >= MlpUnitBase<P>::value) { pass = P; ubase = MlpUnitBase<P>::value; }
+  MLP_PASS_OF(1) MLP_PASS_OF(2) MLP_PASS_OF(3) MLP_PASS_OF(4) MLP_PASS_OF(5) MLP_PASS_OF(6)
+#undef MLP_PASS_OF
+  const int u = unit - ubase, nq = (pass == 4) ? 1 : 2, kt_n = (pass == 1) ? 4 : (pass == 0 || pass == 4) ? 1 : 2;
+  static_assert(mlp_pass(4).nq == 1 && mlp_pass(1).kt == 4 && mlp_pass(0).kt == 1 && mlp_pass(4).kt == 1 && mlp_pass(2).kt == 2 && mlp_pass(3).kt == 2 &&
+                mlp_pass(5).kt == 2 && mlp_pass(6).kt == 2, "the pass table and its run-time copy disagree");
+  const int c = u / nq, q = u % nq, tile = c / kt_n, kt = c % kt_n;
+  const int out = 32 * tile + m, k = 32 * kt + 16 * q + (j & 3) + 8 * (j >> 2) + 4 * g;
   const MlpNet N = mlp_net(Pm, D, A, net);
-  float v;
-  if (e < 32 * kH1) { const int k = e / kH1, n = e % kH1; v = k < D ? N.W1[n * D + k] : 0.0f; }
-  else if (e < 32 * kH1 + kH1 * kH2) { const int q = e - 32 * kH1, k = q / kH2, n = q % kH2; v = N.W2[n * kH1 + k]; }
-  else if (e < 32 * kH1 + kH1 * kH2 + kH2 * kH3) { const int q = e - 32 * kH1 - kH1 * kH2, k = q / kH3, n = q % kH3; v = N.W3[n * kH2 + k]; }
-  else if (e < 32 * kH1 + kH1 * kH2 + kH2 * kH3 + kH3 * 32) { const int q = e - 32 * kH1 - kH1 * kH2 - kH2 * kH3, k = q / 32, n = q % 32; v = n < N.n_out ? N.W4[n * kH3 + k] : 0.0f; }
-  else { const int q = e - 32 * kH1 - kH1 * kH2 - kH2 * kH3 - kH3 * 32, o = q / kH3, k = q % kH3; v = o < N.n_out ? N.W4[o * kH3 + k] : 0.0f; }
-  WT[tid] = v;
-}
-__global__ void mlp_transpose_kernel(const float* __restrict__ Pm, int D, int A, float* __restrict__ WT) {
-  mlp_transpose_element(Pm, D, A, WT, int(blockIdx.x * blockDim.x + threadIdx.x));
+  float v = 0.0f;
+  switch (pass) {
+    case 0: v = k < D ? N.W1[out * D + k] : 0.0f; break;
+    case 1: v = N.W2[out * kH1 + k]; break;
+    case 2: v = N.W3[out * kH2 + k]; break;
+    case 3: v = out < N.n_out ? N.W4[out * kH3 + k] : 0.0f; break;
+    case 4: v = k < N.n_out ? N.W4[k * kH3 + out] : 0.0f; break;
+    case 5: v = N.W3[k * kH2 + out]; break;
+    default: v = N.W2[k * kH1 + out]; break;
+  }
+  uint32_t part[3];
+  split3(v, part[0], part[1], part[2]);
+  uint16_t* dst = WS + (size_t(net) * kMlpFragsPerNet + 3 * unit) * 512 + lane * 8 + j;
+#pragma unroll
+  for (int p = 0; p < 3; p++) dst[p * 512] = uint16_t(part[p] >> 16);
 }
 // Everything the fused kernel needs beforehand in ONE launch (each launch in this chain costs ~4.7 us whatever it does): workgroups
-// [0, adv_blocks) sum the minibatch's advantages (ppo_adv_partials), the rest write the k-major weight copies.  256 threads.
+// [0, adv_blocks) sum the minibatch's advantages (ppo_adv_partials), the rest write the split-weight streams.  256 threads.
 __global__ __launch_bounds__(kPpoBlock) void ppo_mlp_prologue_kernel(const float* __restrict__ adv, int64_t n, double* __restrict__ adv_part,
                                                                      const int64_t* __restrict__ index, int adv_blocks, const float* __restrict__ Pm, int D, int A,
-                                                                     float* __restrict__ WT) {
+                                                                     uint16_t* __restrict__ WS) {
   if (int(blockIdx.x) < adv_blocks) ppo_adv_partials_block(adv, n, adv_part, index, int(blockIdx.x), adv_blocks);   // uniform per workgroup
-  else mlp_transpose_element(Pm, D, A, WT, (int(blockIdx.x) - adv_blocks) * kPpoBlock + int(threadIdx.x));
+  else mlp_pack_element(Pm, D, A, WS, (int(blockIdx.x) - adv_blocks) * kPpoBlock + int(threadIdx.x));
 }
 
-// out[tile] = sum_k Wk[k][32 tile + n] * in[k]  (+ bias), k = 32 t + rowmap(r) + 4 h over the KT input tiles.  Wk is k-major ([K][ld]),
-// zero-padded where a k or an output does not exist: the forward pass gives it W^T, the data-gradient pass the row-major W itself
-// (out index = input neuron).  Every A operand is ONE load "uniform base + per-lane 32-bit offset": `voff` = (4 h ld + n) * 4 bytes is
-// the only address register (passed through an empty asm by the caller once per sample tile, or hipcc hoists all ~600 loop-invariant
-// 64-bit addresses of the kernel out of the tile loop: 400 spilled registers).
-// Order: OUTPUT-tile major, one chunk = the k-steps of one input tile (16 MFMAs, 1024 clocks of matrix-core time -- above the L2 latency
-// of the next chunk's loads, which are issued first).  A finished tile's epilogue (tanh, or the tanh derivative of the backward pass) is
-// spread, element by element, between the MFMAs of the NEXT tile: the vector ALU works in the shadow of the matrix pipe instead of after
-// it (a k-major version with the activations as separate loops spent half of the forward pass outside the MFMAs).
+// out[tile] = W in (+ bias) for pass PASS of the stream: NT output tiles, KT input tiles given as split k-groups in[kt][q].
+// Order: OUTPUT-tile major, one chunk = the k-groups of one input tile (NQ x 6 MFMAs).  Every A operand is ONE 16-byte load "uniform
+// base + per-lane offset" (`voff` = 16 lane: the only address register; passed through an empty asm by the caller once per sample tile,
+// or hipcc hoists the loop-invariant 64-bit addresses of the whole kernel out of the tile loop and spills them), issued two chunks ahead.
+// A finished tile's epilogue (tanh, or the tanh derivative of the backward pass, and the three-way split that makes it the next pass's
+// B operand) is spread, register pair by register pair, between the MFMAs of the NEXT tile: the vector ALU works in the shadow of the
+// matrix pipe instead of after it.
 enum { kEpiNone = 0, kEpiTanh = 1, kEpiDtanh = 2 };
-template <int KT, int NT, int RSTEPS, int LD, int EPI>
-__device__ __forceinline__ void mlp_layer(const float* __restrict__ Wk, const float* __restrict__ bias, int n_valid, const f32x16* in, f32x16* out, uint32_t voff, int h,
-                                          const f32x16* act = nullptr) {
-  constexpr int CH = RSTEPS, NCH = NT * KT, SLOTS = KT * CH;      // chunk stream: (output tile, input tile); MFMA slots per output tile
-  constexpr int EPS = (16 + SLOTS - 1) / SLOTS;                    // epilogue elements placed after each MFMA (1 when SLOTS >= 16)
+template <int PASS, int EPI, bool SPLIT>
+__device__ __forceinline__ void mlp_layer(const u32x4* __restrict__ WSnet, const float* __restrict__ bias, int n_valid, const Bf3 (*in)[2], f32x16* out, Bf3 (*outS)[2],
+                                          uint32_t voff, int h, const f32x16* act = nullptr) {
+  constexpr int NT = mlp_pass(PASS).nt, KT = mlp_pass(PASS).kt, NQ = mlp_pass(PASS).nq;
+  constexpr int NCH = NT * KT, FR = 3 * NQ, SLOTS = KT * NQ * 6;   // chunks; fragments per chunk; MFMA slots per output tile
+  constexpr int STRIDE = SLOTS / 8 > 0 ? SLOTS / 8 : 1, PER = (8 + SLOTS - 1) / SLOTS;   // epilogue pairs: one every STRIDE slots, or PER per slot
+  constexpr int FBASE = 3 * MlpUnitBase<PASS>::value;
 #pragma unroll
   for (int tile = 0; tile < NT; tile++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int row = 32 * tile + mlp_rowmap(r) + 4 * h;
-      out[tile][r] = (bias && row < n_valid) ? bias[row] : 0.0f;
+      out[tile][r] = PASS < 4 ? (row < n_valid ? bias[row < n_valid ? row : 0] : 0.0f) : 0.0f;   // forward passes; clamped address + select: no branch
     }
-  auto epi = [&](int tile, int r) {
-    if (EPI == kEpiTanh) out[tile][r] = tanh_acc(out[tile][r]);
-    else if (EPI == kEpiDtanh) out[tile][r] *= fma_(-act[tile][r], act[tile][r], 1.0f);
+  auto epi = [&](int tile, int e) {   // registers 2 e, 2 e + 1
+    float v0 = out[tile][2 * e], v1 = out[tile][2 * e + 1];
+    if (EPI == kEpiTanh) { v0 = tanh_acc(v0); v1 = tanh_acc(v1); }
+    else if (EPI == kEpiDtanh) { v0 *= fma_(-act[tile][2 * e], act[tile][2 * e], 1.0f); v1 *= fma_(-act[tile][2 * e + 1], act[tile][2 * e + 1], 1.0f); }
+    out[tile][2 * e] = v0; out[tile][2 * e + 1] = v1;
+    if (SPLIT) split_pair(v0, v1, outS[tile][e >> 2], e & 3);
   };
-  float a[2][CH];
-  auto load = [&](int c, int buf) {
+  u32x4 a[3][FR];
+  auto load = [&](int c, int slot) {   // address = uniform base + (per-lane offset + 4-KB group: one VALU add per group) + immediate < 4 KB
 #pragma unroll
-    for (int j = 0; j < CH; j++)
-      a[buf][j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Wk + (32 * (c % KT) + mlp_rowmap(j)) * LD + 32 * (c / KT)) + voff);   // + 4 h: in voff
+    for (int f = 0; f < FR; f++) {
+      const uint32_t at = uint32_t(FBASE + c * FR + f) * 1024u;
+      a[slot][f] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(WSnet) + size_t(voff + (at & ~4095u)) + (at & 4095u));
+    }
   };
   load(0, 0);
+  if (NCH > 1) load(1, 1);
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    if (c + 1 < NCH) load(c + 1, (c + 1) & 1);
+    if (c + 2 < NCH) load(c + 2, (c + 2) % 3);
     const int tile = c / KT, kt = c % KT;
 #pragma unroll
-    for (int j = 0; j < CH; j++) {
-      out[tile] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][j], in[kt][j], out[tile], 0, 0, 0);
-      if (EPI != kEpiNone && tile > 0) {
-        const int slot = kt * CH + j;
-        if (SLOTS >= 16) { if (slot % (SLOTS / 16) == 0) epi(tile - 1, slot / (SLOTS / 16)); }
-        else {
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
-          for (int e = 0; e < EPS; e++) if (slot * EPS + e < 16) epi(tile - 1, slot * EPS + e);
+      for (int i = 0; i < 6; i++) {
+        out[tile] = mfma_bf16(a[c % 3][3 * q + prod_a(i)], in[kt][q].p[prod_b(i)], out[tile]);
+        if ((EPI != kEpiNone || SPLIT) && tile > 0) {
+          const int slot = (kt * NQ + q) * 6 + i;
+          if (SLOTS >= 8) { if (slot % STRIDE == 0 && slot / STRIDE < 8) epi(tile - 1, slot / STRIDE); }
+          else {
+#pragma unroll
+            for (int e = 0; e < PER; e++) if (slot * PER + e < 8) epi(tile - 1, slot * PER + e);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-    }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (EPI != kEpiNone) {
+  if (EPI != kEpiNone || SPLIT) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) epi(NT - 1, r);
+    for (int e = 0; e < 8; e++) epi(NT - 1, e);
   }
 }
 
@@ -160,20 +240,7 @@ __device__ __forceinline__ void xpose_store(float* buf, int row0, const f32x16* 
 // transposes, lane n = neuron within the tile); bsum += this lane half's share of sum_s dZ[row n][s].
 template <int NI>
 __device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ, int zrow, const float* bufH, int hrow, int n, int h) {
-#ifndef MLP_DW_CHUNK
-#define MLP_DW_CHUNK 8
-#endif
-#ifdef MLP_DW_OLD
-#pragma unroll 4
-  for (int t = 0; t < 64; t++) {
-    const float a = bufZ[(zrow + n) * kXs + 2 * t + h];
-    bsum += a;
-#pragma unroll
-    for (int i = 0; i < NI; i++) d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bufH[(hrow + 32 * i + n) * kXs + 2 * t + h], d[i], 0, 0, 0);
-  }
-  return;
-#endif
-  constexpr int CH = MLP_DW_CHUNK / NI, NCH = 64 / CH;                 // LDS reads one chunk ahead of the MFMAs that use them
+  constexpr int CH = 8 / NI, NCH = 64 / CH;                 // LDS reads one chunk ahead of the MFMAs that use them
   const float* pz = bufZ + (zrow + n) * kXs + h;
   const float* ph = bufH + (hrow + n) * kXs + h;
   float a[2][CH], b[2][CH][NI];
@@ -215,7 +282,7 @@ __device__ __forceinline__ void mlp_tile_out(float* slab, int stride, int row0, 
 
 struct MlpLoss { float clip, vf_coef, inv_n, mu, inv_sd; };
 
-#ifdef AMENV_MLP_STAMPS   // diagnostic build: clocks per phase (forward, loss, weight gradients, data gradients), summed into stats slots 11..14
+#ifdef AMENV_MLP_STAMPS   // diagnostic build: clocks per phase (forward, loss, weight gradients, data gradients, LDS publish incl. barriers), summed into stats slots 11..15
 #define MLP_T0() unsigned long long t_ = __builtin_readcyclecounter()
 #define MLP_TK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_readcyclecounter(); tph[k] += float(n_ - t_); t_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -225,14 +292,14 @@ struct MlpLoss { float clip, vf_coef, inv_n, mu, inv_sd; };
 
 // One PPO minibatch: forward + loss + backward + weight gradients of both nets.  grid = (blocks, 2), 256 threads.
 template <int D, int A>
-__global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restrict__ Pm, const float* __restrict__ WT, const float* __restrict__ obs,
+__global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restrict__ Pm, const u32x4* __restrict__ WS, const float* __restrict__ obs,
                                                             const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
                                                             const float* __restrict__ ret, const int64_t* __restrict__ index, int64_t n, float clip,
                                                             float vf_coef, int normalize, const double* __restrict__ adv_part, int adv_blocks,
                                                             float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // transposes [kXposeRows][kXs] | stats [4 wavefronts][16]
-  float* xb = lds;
-  float* lstats = lds + kXposeRows * kXs;
+  extern __shared__ __attribute__((aligned(16))) float mlp_lds[];   // transposes [kXposeRows][kXs] | stats [4 wavefronts][16]
+  float* xz = mlp_lds;
+  float* lstats = mlp_lds + kXposeRows * kXs;
   const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63, nn = lane & 31, h = lane >> 5;
   const int col = wave * 32 + nn;                          // this lane's sample column in the transposes
   const int net = blockIdx.y;
@@ -248,16 +315,14 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     Lp.inv_sd = 1.0f / (float(sqrt(var)) + 1e-8f);
   }
   const MlpNet N = mlp_net(Pm, D, A, net);
-  const float* wt = WT + net * kMlpWtPerNet;
-  const float *W1T = wt, *W2T = wt + 32 * kH1, *W3T = W2T + kH1 * kH2, *W4T = W3T + kH2 * kH3, *W4P = W4T + kH3 * 32;
-  // per-lane byte offsets of the A-operand loads, one per leading dimension: (4 h ld + n) * 4
-  uint32_t vo128 = uint32_t(4 * h * 128 + nn) * 4u, vo64 = uint32_t(4 * h * 64 + nn) * 4u, vo32 = uint32_t(4 * h * 32 + nn) * 4u;
+  const u32x4* ws = WS + size_t(net) * kMlpFragsPerNet * 64;
+  uint32_t voff = uint32_t(lane) * 16u;                    // per-lane byte offset of every A-operand load
   float els[4], isd[4];                                   // log_std / 1 / std of this lane's four head rows (actor)
 #pragma unroll
   for (int r = 0; r < 4; r++) { const int k = r + 4 * h; els[r] = k < A ? Pm[k] : 0.0f; isd[r] = __expf(-els[r]); }
   float s_dls[4] = {0, 0, 0, 0}, s_pol = 0.0f, s_val = 0.0f, s_clipn = 0.0f;
 #ifdef AMENV_MLP_STAMPS
-  float tph[4] = {0, 0, 0, 0};
+  float tph[5] = {0, 0, 0, 0, 0};
 #endif
   // weight-gradient tiles this wavefront owns, accumulated over every sample the workgroup sees:
   //   dW1 [128 x 32]: o-tile = wave            dW2 [64 x 128]: o-tile = wave >> 1, i-tiles 2 (wave & 1) + {0, 1}
@@ -270,24 +335,32 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
   const int64_t iters = (ntiles + int64_t(gridDim.x) * 4 - 1) / (int64_t(gridDim.x) * 4);   // the same for every wavefront: barriers inside
   for (int64_t it = 0; it < iters; it++) {
     const int64_t tile = (int64_t(blockIdx.x) * iters + it) * 4 + wave;
-    asm volatile("" : "+v"(vo128), "+v"(vo64), "+v"(vo32));   // keep the A-operand addresses inside the loop (see mlp_layer)
+    asm volatile("" : "+v"(voff));   // keep the A-operand addresses inside the loop (see mlp_layer)
     const int64_t s = tile * 32 + nn;
     const bool sv = s < n;
     const int64_t sl = sv ? s : n - 1;
-#ifdef MLP_NO_INDEX
-    const int64_t sc = sl;
-#else
     const int64_t sc = index ? index[sl] : sl;            // row of this sample in the rollout tensors
-#endif
     // ---- forward
     MLP_T0();
     f32x16 X[1], H1[4], H2[2], H3[2], Y[1];
 #pragma unroll
-    for (int r = 0; r < 16; r++) { const int k = mlp_rowmap(r) + 4 * h; X[0][r] = (sv && k < D) ? obs[sc * D + k] : 0.0f; }
-    mlp_layer<1, 4, 16, kH1, kEpiTanh>(W1T, N.b1, kH1, X, H1, vo128, h);
-    mlp_layer<4, 2, 16, kH2, kEpiTanh>(W2T, N.b2, kH2, H1, H2, vo64, h);
-    mlp_layer<2, 2, 16, kH3, kEpiTanh>(W3T, N.b3, kH3, H2, H3, vo64, h);
-    mlp_layer<2, 1, 16, 32, kEpiNone>(W4T, N.b4, N.n_out, H3, Y, vo32, h);
+    for (int r = 0; r < 16; r++) { const int k = mlp_rowmap(r) + 4 * h; const float x = obs[sc * D + (k < D ? k : D - 1)]; X[0][r] = (sv && k < D) ? x : 0.0f; }
+    // the loss inputs of this sample, fetched now (HBM latency: nothing in the forward pass depends on them)
+    float act4[4], olp_s, adv_s;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int k = r + 4 * h; act4[r] = net == 0 ? actions[sc * A + (k < A ? k : A - 1)] : 0.0f; }   // (rows >= A are masked where used)
+    olp_s = net == 0 ? old_logp[sc] : 0.0f;
+    adv_s = net == 0 ? adv[sc] : ret[sc];                  // critic: the return
+    {
+      Bf3 XS[1][2], H1S[4][2];
+      split_tile(X[0], XS[0]);
+      mlp_layer<0, kEpiTanh, true>(ws, N.b1, kH1, XS, H1, H1S, voff, h);
+      Bf3 H2S[2][2];
+      mlp_layer<1, kEpiTanh, true>(ws, N.b2, kH2, H1S, H2, H2S, voff, h);
+      Bf3 H3S[2][2];
+      mlp_layer<2, kEpiTanh, true>(ws, N.b3, kH3, H2S, H3, H3S, voff, h);
+      mlp_layer<3, kEpiNone, false>(ws, N.b4, N.n_out, H3S, Y, nullptr, voff, h);
+    }
     MLP_TK(0);
     // ---- loss gradient with respect to the head outputs (rows 0..3 in lane half 0, 4..7 in half 1)
     f32x16 dY[1];
@@ -298,12 +371,12 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int k = r + 4 * h;
-        z[r] = k < A ? (actions[sc * A + k] - Y[0][r]) * isd[r] : 0.0f;
+        z[r] = k < A ? (act4[r] - Y[0][r]) * isd[r] : 0.0f;
         lp += k < A ? fma_(-0.5f * z[r], z[r], -els[r]) - 0.918938533204672742f : 0.0f;
       }
       lp += __shfl_xor(lp, 32);
-      const float ratio = __expf(lp - old_logp[sc]);
-      const float a = (adv[sc] - Lp.mu) * Lp.inv_sd;
+      const float ratio = __expf(lp - olp_s);
+      const float a = (adv_s - Lp.mu) * Lp.inv_sd;
       const float s1 = a * ratio, s2 = a * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
       const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
       const float g_lp = (sv && (inside || s1 < s2)) ? -a * ratio * Lp.inv_n : 0.0f;
@@ -314,49 +387,56 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
       }
       if (sv && h == 0) { s_pol += -fminf(s1, s2); s_clipn += fabsf(ratio - 1.0f) > clip ? 1.0f : 0.0f; }
     } else if (h == 0) {
-      const float dv = ret[sc] - Y[0][0];
+      const float dv = adv_s - Y[0][0];
       dY[0][0] = sv ? -2.0f * vf_coef * dv * Lp.inv_n : 0.0f;
       if (sv) s_val += dv * dv;
     }
+    Bf3 dYS[1][2];
+    split_tile<1>(dY[0], dYS[0]);                           // rows 0..15 are all the head pass reads
     MLP_TK(1);
-    // ---- backward.  Per layer: every wavefront publishes its samples' dZ and layer inputs, barrier, the owned dW tiles accumulate over the
-    // workgroup's 128 samples while the data gradient of the next layer (registers only) is formed, barrier before the area is rewritten.
-    float* xz = xb;                 // dZ rows
+    // ---- backward.  Per layer: every wavefront publishes its samples' split dZ and layer inputs, barrier, the owned dW tiles accumulate over
+    // the workgroup's 128 samples, then the data gradient of the next layer (registers only) is formed; barrier before the area is rewritten.
     // head: dZ4 = dY (32 rows, 8 used), inputs H3 (64 rows)
     __syncthreads();                // (previous iteration's readers are done)
     xpose_store<1>(xz, 0, dY, col, h);
     xpose_store<2>(xz, 32, H3, col, h);
     __syncthreads();
+    MLP_TK(4);
     if (wave < 2) mlp_dw<1>(gW4, gb4, xz, 0, xz, 32 + 32 * wave, nn, h);
     MLP_TK(2);
     f32x16 dZ3[2];
-    mlp_layer<1, 2, 4, kH3, kEpiDtanh>(W4P, nullptr, 0, dY, dZ3, vo64, h, H3);     // dZ3 = (W4^T dY) (1 - H3^2)  (rows 0..7 of dY only)
+    Bf3 dZ3S[2][2];
+    mlp_layer<4, kEpiDtanh, true>(ws, nullptr, 0, dYS, dZ3, dZ3S, voff, h, H3);     // dZ3 = (W4^T dY) (1 - H3^2)  (rows 0..15 of dY only)
     MLP_TK(3);
     // layer 3: dZ3 (64 rows), inputs H2 (64 rows)
     __syncthreads();
     xpose_store<2>(xz, 0, dZ3, col, h);
     xpose_store<2>(xz, 64, H2, col, h);
     __syncthreads();
+    MLP_TK(4);
     mlp_dw<1>(gW3, gb3, xz, 32 * (wave >> 1), xz, 64 + 32 * (wave & 1), nn, h);
     MLP_TK(2);
     f32x16 dZ2[2];
-    mlp_layer<2, 2, 16, kH2, kEpiDtanh>(N.W3, nullptr, 0, dZ3, dZ2, vo64, h, H2);  // dZ2 = (W3^T dZ3) (1 - H2^2)
+    Bf3 dZ2S[2][2];
+    mlp_layer<5, kEpiDtanh, true>(ws, nullptr, 0, dZ3S, dZ2, dZ2S, voff, h, H2);    // dZ2 = (W3^T dZ3) (1 - H2^2)
     MLP_TK(3);
     // layer 2: dZ2 (64 rows), inputs H1 (128 rows)
     __syncthreads();
     xpose_store<2>(xz, 0, dZ2, col, h);
     xpose_store<4>(xz, 64, H1, col, h);
     __syncthreads();
+    MLP_TK(4);
     mlp_dw<2>(gW2, gb2, xz, 32 * (wave >> 1), xz, 64 + 64 * (wave & 1), nn, h);
     MLP_TK(2);
     f32x16 dZ1[4];
-    mlp_layer<2, 4, 16, kH1, kEpiDtanh>(N.W2, nullptr, 0, dZ2, dZ1, vo128, h, H1); // dZ1 = (W2^T dZ2) (1 - H1^2)
+    mlp_layer<6, kEpiDtanh, false>(ws, nullptr, 0, dZ2S, dZ1, nullptr, voff, h, H1); // dZ1 = (W2^T dZ2) (1 - H1^2)
     MLP_TK(3);
     // layer 1: dZ1 (128 rows), inputs = the observation tile (32 rows)
     __syncthreads();
     xpose_store<4>(xz, 0, dZ1, col, h);
     xpose_store<1>(xz, 128, X, col, h);
     __syncthreads();
+    MLP_TK(4);
     mlp_dw<1>(gW1, gb1, xz, 32 * wave, xz, 128, nn, h);
     MLP_TK(2);
   }
@@ -389,7 +469,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
         if (h == 0) { ws_[8] = vals[4]; ws_[10] = vals[6]; }
       } else if (h == 0) ws_[9] = vals[5];
 #ifdef AMENV_MLP_STAMPS
-      if (h == 0) for (int k = 0; k < 4; k++) ws_[11 + k] = tph[k];
+      if (h == 0) for (int k = 0; k < 5; k++) ws_[11 + k] = tph[k];
 #endif
     }
   }

@@ -14,11 +14,11 @@ torch.cuda.synchronize()
 if "mlpstamps" in os.environ.get("AMENV_LIB", ""):
     import numpy as np
     ws = step._mlp_ws.view(torch.float32)
-    adv_b, wt = 2 * 1024 * 2, 2 * (32*128 + 128*64 + 64*64 + 64*32 + 32*64)
+    adv_b, wt = 2 * 1024 * 2, 2 * 186 * 256   # floats: advantage partials (doubles), split-weight streams (186 KB per net)
     acc_size = 128*33 + 64*129 + 64*65 + 32*65 + 16
     blocks = 128
     part = ws[adv_b + wt: adv_b + wt + 2 * blocks * acc_size].reshape(2, blocks, acc_size).cpu().numpy()
-    st = part[:, :, acc_size - 16 + 11: acc_size - 16 + 15]          # [net][block][phase]: sums over the 4 waves' lane 0
+    st = part[:, :, acc_size - 16 + 11: acc_size - 16 + 16]          # [net][block][phase]: sums over the 4 waves' lane 0
     per_wave = st.sum(1) / (blocks * 4)
     for net in (0, 1):
-        print("net", net, "clocks per wave: forward %.0f  loss %.0f  weight-grad %.0f  data-grad %.0f  total %.0f" % (*per_wave[net], per_wave[net].sum()))
+        print("net", net, "clocks per wave: forward %.0f  loss %.0f  weight-grad %.0f  data-grad %.0f  publish %.0f  total %.0f" % (*per_wave[net], per_wave[net].sum()))
