@@ -44,9 +44,10 @@ constexpr int kH1 = 128, kH2 = 64, kH3 = 64;
 // per-workgroup gradient accumulator (floats): dW1 [128][33] (col 32 = bias) | dW2 [64][129] | dW3 [64][65] | dW4 [32][65] | stats [16]
 constexpr int kAccW1 = 0, kAccW2 = kAccW1 + kH1 * 33, kAccW3 = kAccW2 + kH2 * 129, kAccW4 = kAccW3 + kH3 * 65, kAccStats = kAccW4 + 32 * 65;
 constexpr int kAccSize = kAccStats + 16;
-constexpr int kXs = 129;                                                      // transpose row stride: 4 wavefronts x 32 samples + 1
+constexpr int kXs = 132;                                                      // transpose row stride (floats): 4 wavefronts x 32 samples + 4 -- 16-byte rows for
+                                                                              // the ds_read_b128 of mlp_dw, 16 consecutive rows on 16 different bank quads
 constexpr int kXposeRows = 192;                                               // largest layer: dZ2 (64 rows) + H1 (128 rows)
-constexpr int kMlpLdsBytes = (kXposeRows * kXs + 64) * 4;                     // + stats [4 wavefronts][16]
+constexpr int kMlpLdsBytes = (kXposeRows * kXs + 64 + kH1 + kH2 + kH3 + 32) * 4;  // + stats [4 wavefronts][16] + the net's biases
 constexpr int kMlpMaxBlocks = 256;
 
 // The split-weight stream of one net: passes in the order the kernel runs them; a pass = NT output tiles x KT input tiles chunks, a chunk =
@@ -169,48 +170,84 @@ __global__ __launch_bounds__(kPpoBlock) void ppo_mlp_prologue_kernel(const float
 // B operand) is spread, register pair by register pair, between the MFMAs of the NEXT tile: the vector ALU works in the shadow of the
 // matrix pipe instead of after it.
 enum { kEpiNone = 0, kEpiTanh = 1, kEpiDtanh = 2 };
-template <int PASS, int EPI, bool SPLIT>
-__device__ __forceinline__ void mlp_layer(const u32x4* __restrict__ WSnet, const float* __restrict__ bias, int n_valid, const Bf3 (*in)[2], f32x16* out, Bf3 (*outS)[2],
-                                          uint32_t voff, int h, const f32x16* act = nullptr) {
-  constexpr int NT = mlp_pass(PASS).nt, KT = mlp_pass(PASS).kt, NQ = mlp_pass(PASS).nq;
-  constexpr int NCH = NT * KT, FR = 3 * NQ, SLOTS = KT * NQ * 6;   // chunks; fragments per chunk; MFMA slots per output tile
-  constexpr int STRIDE = SLOTS / 8 > 0 ? SLOTS / 8 : 1, PER = (8 + SLOTS - 1) / SLOTS;   // epilogue pairs: one every STRIDE slots, or PER per slot
-  constexpr int FBASE = 3 * MlpUnitBase<PASS>::value;
+// epilogue of registers 2 e, 2 e + 1 of one finished tile: activation (or its derivative against the forward activation `act`), split
+template <int EPI, bool SPLIT>
+__device__ __forceinline__ void mlp_epi_pair(f32x16& out, const f32x16* act, Bf3* outS, int e) {
+  float v0 = out[2 * e], v1 = out[2 * e + 1];
+  if (EPI == kEpiTanh) { v0 = tanh_acc(v0); v1 = tanh_acc(v1); }
+  else if (EPI == kEpiDtanh) { v0 *= fma_(-(*act)[2 * e], (*act)[2 * e], 1.0f); v1 *= fma_(-(*act)[2 * e + 1], (*act)[2 * e + 1], 1.0f); }
+  out[2 * e] = v0; out[2 * e + 1] = v1;
+  if (SPLIT) split_pair(v0, v1, outS[e >> 2], e & 3);
+}
+// accumulators of a forward pass = its bias, from the copy the workgroup keeps in LDS ([b1 128 | b2 64 | b3 64 | b4 padded to 32]: ~120
+// clocks before the pass's first MFMA instead of an L2 round trip; all lanes of a half read the same 16 bytes)
+constexpr int kBiasFloats = kH1 + kH2 + kH3 + 32;
+template <int PASS>
+__device__ __forceinline__ void mlp_bias_init(const float* lbias, f32x16* out, int h) {
+  constexpr int NT = mlp_pass(PASS).nt, OFF = PASS == 0 ? 0 : PASS == 1 ? kH1 : PASS == 2 ? kH1 + kH2 : kH1 + kH2 + kH3;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int tile = 0; tile < NT; tile++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = 32 * tile + mlp_rowmap(r) + 4 * h;
-      out[tile][r] = PASS < 4 ? (row < n_valid ? bias[row < n_valid ? row : 0] : 0.0f) : 0.0f;   // forward passes; clamped address + select: no branch
-    }
-  auto epi = [&](int tile, int e) {   // registers 2 e, 2 e + 1
-    float v0 = out[tile][2 * e], v1 = out[tile][2 * e + 1];
-    if (EPI == kEpiTanh) { v0 = tanh_acc(v0); v1 = tanh_acc(v1); }
-    else if (EPI == kEpiDtanh) { v0 *= fma_(-act[tile][2 * e], act[tile][2 * e], 1.0f); v1 *= fma_(-act[tile][2 * e + 1], act[tile][2 * e + 1], 1.0f); }
-    out[tile][2 * e] = v0; out[tile][2 * e + 1] = v1;
-    if (SPLIT) split_pair(v0, v1, outS[tile][e >> 2], e & 3);
-  };
-  u32x4 a[3][FR];
-  auto load = [&](int c, int slot) {   // address = uniform base + (per-lane offset + 4-KB group: one VALU add per group) + immediate < 4 KB
+    for (int g4 = 0; g4 < 4; g4++) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + OFF + 32 * tile + 8 * g4 + 4 * h);
 #pragma unroll
-    for (int f = 0; f < FR; f++) {
-      const uint32_t at = uint32_t(FBASE + c * FR + f) * 1024u;
-      a[slot][f] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(WSnet) + size_t(voff + (at & ~4095u)) + (at & 4095u));
+      for (int k = 0; k < 4; k++) out[tile][4 * g4 + k] = b[k];
     }
-  };
-  load(0, 0);
-  if (NCH > 1) load(1, 1);
+}
+struct MlpNoPrev { __device__ __forceinline__ void operator()(int) const {} };
+// The A-operand ring: three chunks of up to six fragments.  The forward passes run as ONE chunk stream through it (SLOT0 = first slot of a
+// pass, PRELOADED = its chunks 0 and 1 were fetched by the pass before, NEXT = the pass whose chunks 0 and 1 this one fetches during its
+// last two chunks): a pass that starts cold waits an L2 round trip (~700 clocks) before its first MFMA.
+struct MlpRing { u32x4 a[3][6]; };
+template <int PASS>
+__device__ __forceinline__ void mlp_ring_load(MlpRing& R, const u32x4* __restrict__ WSnet, uint32_t voff, int c, int slot) {
+  constexpr int FR = 3 * mlp_pass(PASS).nq, FBASE = 3 * MlpUnitBase<PASS>::value;
+#pragma unroll
+  for (int f = 0; f < FR; f++) {   // address = uniform base + (per-lane offset + 4-KB group: one VALU add per group) + immediate < 4 KB
+    const uint32_t at = uint32_t(FBASE + c * FR + f) * 1024u;
+    R.a[slot][f] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(WSnet) + size_t(voff + (at & ~4095u)) + (at & 4095u));
+  }
+}
+// `prev`: the epilogue pairs of the LAST tile of the pass before (which made this pass's last input tile), run between the MFMAs of this
+// pass's first chunks -- those read the earlier input tiles only -- when PREV is set (needs KT >= 2); a pass whose successor does that
+// is called with DEFER and leaves its last tile unfinished.
+template <int PASS, int EPI, bool SPLIT, int SLOT0 = 0, bool PRELOADED = false, int NEXT = -1, bool DEFER = false, bool PREV = false, class Prev = MlpNoPrev>
+__device__ __forceinline__ void mlp_layer(MlpRing& R, const u32x4* __restrict__ WSnet, const float* lbias, const Bf3 (*in)[2], f32x16* out,
+                                          Bf3 (*outS)[2], uint32_t voff, int h, const f32x16* act = nullptr, Prev prev = Prev()) {
+  constexpr int NT = mlp_pass(PASS).nt, KT = mlp_pass(PASS).kt, NQ = mlp_pass(PASS).nq;
+  constexpr int NCH = NT * KT, SLOTS = KT * NQ * 6;                // chunks; MFMA slots per output tile
+  constexpr int STRIDE = SLOTS / 8 > 0 ? SLOTS / 8 : 1, PER = (8 + SLOTS - 1) / SLOTS;   // epilogue pairs: one every STRIDE slots, or PER per slot
+  constexpr int PSLOTS = (KT - 1) * NQ * 6, PSTRIDE = PSLOTS / 8 > 0 ? PSLOTS / 8 : 1;   // slots and spacing for the pass before's pairs
+  static_assert(!PREV || PSLOTS >= 8, "the deferred epilogue needs eight MFMA slots before the last input tile is read");
+  if (PASS < 4) mlp_bias_init<PASS>(lbias, out, h);
+  else {
+#pragma unroll
+    for (int tile = 0; tile < NT; tile++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) out[tile][r] = 0.0f;
+  }
+  auto epi = [&](int tile, int e) { mlp_epi_pair<EPI, SPLIT>(out[tile], act ? act + tile : nullptr, SPLIT ? outS[tile] : nullptr, e); };
+  if (!PRELOADED) {
+    mlp_ring_load<PASS>(R, WSnet, voff, 0, SLOT0 % 3);
+    if (NCH > 1) mlp_ring_load<PASS>(R, WSnet, voff, 1, (SLOT0 + 1) % 3);
+  }
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    if (c + 2 < NCH) load(c + 2, (c + 2) % 3);
+    if (c + 2 < NCH) mlp_ring_load<PASS>(R, WSnet, voff, c + 2, (SLOT0 + c + 2) % 3);
+    else if (NEXT >= 0) mlp_ring_load<(NEXT >= 0 ? NEXT : 0)>(R, WSnet, voff, c + 2 - NCH, (SLOT0 + c + 2) % 3);
     const int tile = c / KT, kt = c % KT;
 #pragma unroll
     for (int q = 0; q < NQ; q++)
 #pragma unroll
       for (int i = 0; i < 6; i++) {
-        out[tile] = mfma_bf16(a[c % 3][3 * q + prod_a(i)], in[kt][q].p[prod_b(i)], out[tile]);
+        out[tile] = mfma_bf16(R.a[(SLOT0 + c) % 3][3 * q + prod_a(i)], in[kt][q].p[prod_b(i)], out[tile]);
+        const int slot = (kt * NQ + q) * 6 + i;
+        if (PREV && tile == 0 && kt < KT - 1) {
+          if (slot % PSTRIDE == 0 && slot / PSTRIDE < 8) prev(slot / PSTRIDE);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if ((EPI != kEpiNone || SPLIT) && tile > 0) {
-          const int slot = (kt * NQ + q) * 6 + i;
           if (SLOTS >= 8) { if (slot % STRIDE == 0 && slot / STRIDE < 8) epi(tile - 1, slot / STRIDE); }
           else {
 #pragma unroll
@@ -221,7 +258,7 @@ __device__ __forceinline__ void mlp_layer(const u32x4* __restrict__ WSnet, const
       }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (EPI != kEpiNone || SPLIT) {
+  if ((EPI != kEpiNone || SPLIT) && !DEFER) {
 #pragma unroll
     for (int e = 0; e < 8; e++) epi(NT - 1, e);
   }
@@ -237,37 +274,50 @@ __device__ __forceinline__ void xpose_store(float* buf, int row0, const f32x16* 
 }
 
 // d[i] += sum over the workgroup's 128 samples of dZ[o-tile][s] H[i-tile][s] for NI input tiles (row = 32-row tile index in the LDS
-// transposes, lane n = neuron within the tile); bsum += this lane half's share of sum_s dZ[row n][s].
+// transposes, lane (n, g) = neuron n of the tile, samples 16 kq + 8 g .. + 7 of every k-group kq: two ds_read_b128 per operand);
+// bsum += this lane's share of sum_s dZ[row n][s].  The fp32 values are split three ways HERE, by the wavefront that consumes them
+// (11 VALU instructions per pair of values, in the shadow of the previous k-group's MFMAs): 6 bf16 MFMAs per 16 samples instead of
+// 8 fp32 ones at twice the clocks each.  (Publishing the split parts instead -- three bf16 planes [sample][row], written as 8-byte
+// chunks and read back with ds_read_b64_tr_b16 -- was built and is correct, but its extra splitting and LDS stores on the publishing side
+// cost more than the reads here save: 167 us per 65,536 samples against 149 with fp32 MFMAs in this function.)
 template <int NI>
-__device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ, int zrow, const float* bufH, int hrow, int n, int h) {
-  constexpr int CH = 8 / NI, NCH = 64 / CH;                 // LDS reads one chunk ahead of the MFMAs that use them
-  const float* pz = bufZ + (zrow + n) * kXs + h;
-  const float* ph = bufH + (hrow + n) * kXs + h;
-  float a[2][CH], b[2][CH][NI];
-  auto load = [&](int buf) {
+__device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ, int zrow, const float* bufH, int hrow, int n, int g) {
+  const float* pz = bufZ + (zrow + n) * kXs + 8 * g;
+  const float* ph = bufH + (hrow + n) * kXs + 8 * g;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 a[2][2], b[2][NI][2];
+  auto load = [&](int buf) {   // LDS reads one k-group ahead of the MFMAs that use them
 #pragma unroll
-    for (int j = 0; j < CH; j++) {
-      a[buf][j] = pz[2 * j];
+    for (int k = 0; k < 2; k++) {
+      a[buf][k] = *reinterpret_cast<const f32x4*>(pz + 4 * k);
 #pragma unroll
-      for (int i = 0; i < NI; i++) b[buf][j][i] = ph[32 * i * kXs + 2 * j];
+      for (int i = 0; i < NI; i++) b[buf][i][k] = *reinterpret_cast<const f32x4*>(ph + 32 * i * kXs + 4 * k);
     }
-    pz += 2 * CH; ph += 2 * CH;
+    pz += 16; ph += 16;
+  };
+  auto split8 = [&](const f32x4* v, Bf3& s) {
+#pragma unroll
+    for (int dd = 0; dd < 4; dd++) split_pair(v[dd >> 1][2 * (dd & 1)], v[dd >> 1][2 * (dd & 1) + 1], s, dd);
   };
   auto mac = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < CH; j++) {
-      bsum += a[buf][j];
+    for (int k = 0; k < 2; k++) bsum += (a[buf][k][0] + a[buf][k][1]) + (a[buf][k][2] + a[buf][k][3]);
+    Bf3 as, bs;
+    split8(a[buf], as);
 #pragma unroll
-      for (int i = 0; i < NI; i++) d[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][j], b[buf][j][i], d[i], 0, 0, 0);
+    for (int i = 0; i < NI; i++) {
+      split8(b[buf][i], bs);
+#pragma unroll
+      for (int k = 0; k < 6; k++) d[i] = mfma_bf16(as.p[prod_a(k)], bs.p[prod_b(k)], d[i]);
     }
   };
   load(0);
 #pragma unroll 1
-  for (int c = 0; c < NCH; c += 2) {           // a rolled loop (two chunks per trip): unrolled, the register allocator spills
+  for (int kq = 0; kq < 8; kq += 2) {          // a rolled loop (two k-groups per trip): unrolled, the register allocator spills
     load(1);
     mac(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (c + 2 == NCH) { pz -= 2 * CH; ph -= 2 * CH; }   // last trip: re-read the last chunk instead of running past the row
+    if (kq + 2 == 8) { pz -= 16; ph -= 16; }   // last trip: re-read the last k-group instead of running past the row
     load(0);
     mac(1);
     __builtin_amdgcn_sched_barrier(0);
@@ -303,6 +353,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
   const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63, nn = lane & 31, h = lane >> 5;
   const int col = wave * 32 + nn;                          // this lane's sample column in the transposes
   const int net = blockIdx.y;
+  float* lbias = lstats + 64;                             // [b1 | b2 | b3 | b4 padded to 32 rows]
   if (threadIdx.x < 64) lstats[threadIdx.x] = 0.0f;
   // advantage statistics: every block sums the partials in the same fixed order (as ppo_loss_grad)
   MlpLoss Lp{clip, vf_coef, 1.0f / float(n), 0.0f, 1.0f};
@@ -315,6 +366,11 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     Lp.inv_sd = 1.0f / (float(sqrt(var)) + 1e-8f);
   }
   const MlpNet N = mlp_net(Pm, D, A, net);
+  for (int k = threadIdx.x; k < kBiasFloats; k += 256) {
+    const int k4 = k - (kH1 + kH2 + kH3);
+    lbias[k] = k < kH1 ? N.b1[k] : k < kH1 + kH2 ? N.b2[k - kH1] : k4 < 0 ? N.b3[k - kH1 - kH2] : k4 < N.n_out ? N.b4[k4] : 0.0f;
+  }
+  __syncthreads();
   const u32x4* ws = WS + size_t(net) * kMlpFragsPerNet * 64;
   uint32_t voff = uint32_t(lane) * 16u;                    // per-lane byte offset of every A-operand load
   float els[4], isd[4];                                   // log_std / 1 / std of this lane's four head rows (actor)
@@ -351,15 +407,21 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     for (int r = 0; r < 4; r++) { const int k = r + 4 * h; act4[r] = net == 0 ? actions[sc * A + (k < A ? k : A - 1)] : 0.0f; }   // (rows >= A are masked where used)
     olp_s = net == 0 ? old_logp[sc] : 0.0f;
     adv_s = net == 0 ? adv[sc] : ret[sc];                  // critic: the return
+    MlpRing ring;
     {
       Bf3 XS[1][2], H1S[4][2];
       split_tile(X[0], XS[0]);
-      mlp_layer<0, kEpiTanh, true>(ws, N.b1, kH1, XS, H1, H1S, voff, h);
+      // one chunk stream through the ring: 4 + 8 + 4 + 2 chunks; each pass fetches the next one's first two chunks and leaves its last
+      // tile's tanh + split to the first MFMAs of the next
+      mlp_layer<0, kEpiTanh, true, 0, false, 1, true>(ring, ws, lbias, XS, H1, H1S, voff, h);
       Bf3 H2S[2][2];
-      mlp_layer<1, kEpiTanh, true>(ws, N.b2, kH2, H1S, H2, H2S, voff, h);
+      mlp_layer<1, kEpiTanh, true, 4 % 3, true, 2, true, true>(ring, ws, lbias, H1S, H2, H2S, voff, h, nullptr,
+                                                                [&](int e) { mlp_epi_pair<kEpiTanh, true>(H1[3], nullptr, H1S[3], e); });
       Bf3 H3S[2][2];
-      mlp_layer<2, kEpiTanh, true>(ws, N.b3, kH3, H2S, H3, H3S, voff, h);
-      mlp_layer<3, kEpiNone, false>(ws, N.b4, N.n_out, H3S, Y, nullptr, voff, h);
+      mlp_layer<2, kEpiTanh, true, 12 % 3, true, 3, true, true>(ring, ws, lbias, H2S, H3, H3S, voff, h, nullptr,
+                                                                 [&](int e) { mlp_epi_pair<kEpiTanh, true>(H2[1], nullptr, H2S[1], e); });
+      mlp_layer<3, kEpiNone, false, 16 % 3, true, -1, false, true>(ring, ws, lbias, H3S, Y, nullptr, voff, h, nullptr,
+                                                                    [&](int e) { mlp_epi_pair<kEpiTanh, true>(H3[1], nullptr, H3S[1], e); });
     }
     MLP_TK(0);
     // ---- loss gradient with respect to the head outputs (rows 0..3 in lane half 0, 4..7 in half 1)
@@ -406,7 +468,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     MLP_TK(2);
     f32x16 dZ3[2];
     Bf3 dZ3S[2][2];
-    mlp_layer<4, kEpiDtanh, true>(ws, nullptr, 0, dYS, dZ3, dZ3S, voff, h, H3);     // dZ3 = (W4^T dY) (1 - H3^2)  (rows 0..15 of dY only)
+    mlp_layer<4, kEpiDtanh, true>(ring, ws, nullptr, dYS, dZ3, dZ3S, voff, h, H3);     // dZ3 = (W4^T dY) (1 - H3^2)  (rows 0..15 of dY only)
     MLP_TK(3);
     // layer 3: dZ3 (64 rows), inputs H2 (64 rows)
     __syncthreads();
@@ -418,7 +480,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     MLP_TK(2);
     f32x16 dZ2[2];
     Bf3 dZ2S[2][2];
-    mlp_layer<5, kEpiDtanh, true>(ws, nullptr, 0, dZ3S, dZ2, dZ2S, voff, h, H2);    // dZ2 = (W3^T dZ3) (1 - H2^2)
+    mlp_layer<5, kEpiDtanh, true>(ring, ws, nullptr, dZ3S, dZ2, dZ2S, voff, h, H2);    // dZ2 = (W3^T dZ3) (1 - H2^2)
     MLP_TK(3);
     // layer 2: dZ2 (64 rows), inputs H1 (128 rows)
     __syncthreads();
@@ -429,7 +491,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     mlp_dw<2>(gW2, gb2, xz, 32 * (wave >> 1), xz, 64 + 64 * (wave & 1), nn, h);
     MLP_TK(2);
     f32x16 dZ1[4];
-    mlp_layer<6, kEpiDtanh, false>(ws, nullptr, 0, dZ2S, dZ1, nullptr, voff, h, H1); // dZ1 = (W2^T dZ2) (1 - H1^2)
+    mlp_layer<6, kEpiDtanh, false>(ring, ws, nullptr, dZ2S, dZ1, nullptr, voff, h, H1); // dZ1 = (W2^T dZ2) (1 - H1^2)
     MLP_TK(3);
     // layer 1: dZ1 (128 rows), inputs = the observation tile (32 rows)
     __syncthreads();
