@@ -209,6 +209,11 @@ __device__ __forceinline__ void mlp_ring_load(MlpRing& R, const u32x4* __restric
     R.a[slot][f] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(WSnet) + size_t(voff + (at & ~4095u)) + (at & 4095u));
   }
 }
+template <int PASS>
+__device__ __forceinline__ void mlp_ring_prefetch(MlpRing& R, const u32x4* __restrict__ WSnet, uint32_t voff) {   // chunks 0, 1 -> slots 0, 1
+  mlp_ring_load<PASS>(R, WSnet, voff, 0, 0);
+  if (mlp_pass(PASS).nt * mlp_pass(PASS).kt > 1) mlp_ring_load<PASS>(R, WSnet, voff, 1, 1);
+}
 // `prev`: the epilogue pairs of the LAST tile of the pass before (which made this pass's last input tile), run between the MFMAs of this
 // pass's first chunks -- those read the earlier input tiles only -- when PREV is set (needs KT >= 2); a pass whose successor does that
 // is called with DEFER and leaves its last tile unfinished.
@@ -280,10 +285,10 @@ __device__ __forceinline__ void xpose_store(float* buf, int row0, const f32x16* 
 // 8 fp32 ones at twice the clocks each.  (Publishing the split parts instead -- three bf16 planes [sample][row], written as 8-byte
 // chunks and read back with ds_read_b64_tr_b16 -- was built and is correct, but its extra splitting and LDS stores on the publishing side
 // cost more than the reads here save: 167 us per 65,536 samples against 149 with fp32 MFMAs in this function.)
-template <int NI>
-__device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ, int zrow, const float* bufH, int hrow, int n, int g) {
-  const float* pz = bufZ + (zrow + n) * kXs + 8 * g;
-  const float* ph = bufH + (hrow + n) * kXs + 8 * g;
+template <int NI, int NKQ = 8>
+__device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ, int zrow, const float* bufH, int hrow, int n, int g, int kq0 = 0) {
+  const float* pz = bufZ + (zrow + n) * kXs + 8 * g + 16 * kq0;   // k-groups kq0 .. kq0 + NKQ - 1
+  const float* ph = bufH + (hrow + n) * kXs + 8 * g + 16 * kq0;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4 a[2][2], b[2][NI][2];
   auto load = [&](int buf) {   // LDS reads one k-group ahead of the MFMAs that use them
@@ -313,11 +318,11 @@ __device__ __forceinline__ void mlp_dw(f32x16* d, float& bsum, const float* bufZ
   };
   load(0);
 #pragma unroll 1
-  for (int kq = 0; kq < 8; kq += 2) {          // a rolled loop (two k-groups per trip): unrolled, the register allocator spills
+  for (int kq = 0; kq < NKQ; kq += 2) {        // a rolled loop (two k-groups per trip): unrolled, the register allocator spills
     load(1);
     mac(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (kq + 2 == 8) { pz -= 16; ph -= 16; }   // last trip: re-read the last k-group instead of running past the row
+    if (kq + 2 == NKQ) { pz -= 16; ph -= 16; } // last trip: re-read the last k-group instead of running past the row
     load(0);
     mac(1);
     __builtin_amdgcn_sched_barrier(0);
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
 #endif
   // weight-gradient tiles this wavefront owns, accumulated over every sample the workgroup sees:
   //   dW1 [128 x 32]: o-tile = wave            dW2 [64 x 128]: o-tile = wave >> 1, i-tiles 2 (wave & 1) + {0, 1}
-  //   dW3 [64 x 64] : (wave >> 1, wave & 1)    dW4 [32 x 64] : i-tile = wave (wavefronts 0, 1)
+  //   dW3 [64 x 64] : (wave >> 1, wave & 1)    dW4 [32 x 64] : i-tile = wave & 1, samples 64 (wave >> 1) .. + 63 of the workgroup's 128
   f32x16 gW1[1], gW2[2], gW3[1], gW4[1];
   float gb1 = 0.0f, gb2 = 0.0f, gb3 = 0.0f, gb4 = 0.0f;
 #pragma unroll
@@ -456,43 +461,47 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
     Bf3 dYS[1][2];
     split_tile<1>(dY[0], dYS[0]);                           // rows 0..15 are all the head pass reads
     MLP_TK(1);
-    // ---- backward.  Per layer: every wavefront publishes its samples' split dZ and layer inputs, barrier, the owned dW tiles accumulate over
-    // the workgroup's 128 samples, then the data gradient of the next layer (registers only) is formed; barrier before the area is rewritten.
+    // ---- backward.  Per layer: every wavefront publishes its samples' dZ and layer inputs, barrier; the data gradient of the next layer
+    // (registers only; its first weight chunks were requested before the barriers) is formed, then the owned dW tiles accumulate over the
+    // workgroup's 128 samples; barrier before the area is rewritten.
     // head: dZ4 = dY (32 rows, 8 used), inputs H3 (64 rows)
+    mlp_ring_prefetch<4>(ring, ws, voff);
     __syncthreads();                // (previous iteration's readers are done)
     xpose_store<1>(xz, 0, dY, col, h);
     xpose_store<2>(xz, 32, H3, col, h);
     __syncthreads();
     MLP_TK(4);
-    if (wave < 2) mlp_dw<1>(gW4, gb4, xz, 0, xz, 32 + 32 * wave, nn, h);
-    MLP_TK(2);
     f32x16 dZ3[2];
     Bf3 dZ3S[2][2];
-    mlp_layer<4, kEpiDtanh, true>(ring, ws, nullptr, dYS, dZ3, dZ3S, voff, h, H3);     // dZ3 = (W4^T dY) (1 - H3^2)  (rows 0..15 of dY only)
+    mlp_layer<4, kEpiDtanh, true, 0, true>(ring, ws, nullptr, dYS, dZ3, dZ3S, voff, h, H3);     // dZ3 = (W4^T dY) (1 - H3^2)  (rows 0..15 of dY only)
     MLP_TK(3);
+    mlp_dw<1, 4>(gW4, gb4, xz, 0, xz, 32 + 32 * (wave & 1), nn, h, 4 * (wave >> 1));   // i-tile = wave & 1, half of the samples each: summed at the end
+    MLP_TK(2);
     // layer 3: dZ3 (64 rows), inputs H2 (64 rows)
+    mlp_ring_prefetch<5>(ring, ws, voff);
     __syncthreads();
     xpose_store<2>(xz, 0, dZ3, col, h);
     xpose_store<2>(xz, 64, H2, col, h);
     __syncthreads();
     MLP_TK(4);
-    mlp_dw<1>(gW3, gb3, xz, 32 * (wave >> 1), xz, 64 + 32 * (wave & 1), nn, h);
-    MLP_TK(2);
     f32x16 dZ2[2];
     Bf3 dZ2S[2][2];
-    mlp_layer<5, kEpiDtanh, true>(ring, ws, nullptr, dZ3S, dZ2, dZ2S, voff, h, H2);    // dZ2 = (W3^T dZ3) (1 - H2^2)
+    mlp_layer<5, kEpiDtanh, true, 0, true>(ring, ws, nullptr, dZ3S, dZ2, dZ2S, voff, h, H2);    // dZ2 = (W3^T dZ3) (1 - H2^2)
     MLP_TK(3);
+    mlp_dw<1>(gW3, gb3, xz, 32 * (wave >> 1), xz, 64 + 32 * (wave & 1), nn, h);
+    MLP_TK(2);
     // layer 2: dZ2 (64 rows), inputs H1 (128 rows)
+    mlp_ring_prefetch<6>(ring, ws, voff);
     __syncthreads();
     xpose_store<2>(xz, 0, dZ2, col, h);
     xpose_store<4>(xz, 64, H1, col, h);
     __syncthreads();
     MLP_TK(4);
+    f32x16 dZ1[4];
+    mlp_layer<6, kEpiDtanh, false, 0, true>(ring, ws, nullptr, dZ2S, dZ1, nullptr, voff, h, H1); // dZ1 = (W2^T dZ2) (1 - H1^2)
+    MLP_TK(3);
     mlp_dw<2>(gW2, gb2, xz, 32 * (wave >> 1), xz, 64 + 64 * (wave & 1), nn, h);
     MLP_TK(2);
-    f32x16 dZ1[4];
-    mlp_layer<6, kEpiDtanh, false>(ring, ws, nullptr, dZ2S, dZ1, nullptr, voff, h, H1); // dZ1 = (W2^T dZ2) (1 - H1^2)
-    MLP_TK(3);
     // layer 1: dZ1 (128 rows), inputs = the observation tile (32 rows)
     __syncthreads();
     xpose_store<4>(xz, 0, dZ1, col, h);
@@ -508,7 +517,22 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
   mlp_tile_out(slab + kAccW2, 129, 32 * (wave >> 1), 64 * (wave & 1), gW2[0], nn, h);
   mlp_tile_out(slab + kAccW2, 129, 32 * (wave >> 1), 64 * (wave & 1) + 32, gW2[1], nn, h);
   mlp_tile_out(slab + kAccW3, 65, 32 * (wave >> 1), 32 * (wave & 1), gW3[0], nn, h);
-  if (wave < 2) mlp_tile_out(slab + kAccW4, 65, 0, 32 * wave, gW4[0], nn, h);
+  {   // dW4: wavefronts 2, 3 hand their half-sample sums to 0, 1 through LDS (the transposes are free: every reader passed the last barrier)
+    __syncthreads();
+    float* hand = xz + (wave & 1) * 17 * 64;
+    if (wave >= 2) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) hand[r * 64 + lane] = gW4[0][r];
+      hand[16 * 64 + lane] = gb4;
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) gW4[0][r] += hand[r * 64 + lane];
+      gb4 += hand[16 * 64 + lane];
+      mlp_tile_out(slab + kAccW4, 65, 0, 32 * wave, gW4[0], nn, h);
+    }
+  }
   gb1 += __shfl_xor(gb1, 32); gb2 += __shfl_xor(gb2, 32); gb3 += __shfl_xor(gb3, 32); gb4 += __shfl_xor(gb4, 32);
   if (h == 0) {
     slab[kAccW1 + (32 * wave + nn) * 33 + 32] = gb1;
