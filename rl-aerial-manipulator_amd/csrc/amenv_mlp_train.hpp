@@ -20,12 +20,16 @@
 //   * weights are the A operands: mlp_pack_element (prologue launch, after every optimiser step) writes, per net, the split weights of
 //     the four forward and three data-gradient passes as a stream of 1-KB fragments in exactly the order the kernel consumes them
 //     (chunk = (output tile, input tile) x k-group x part; lane x 8 bf16 = one 16-byte load per lane), L2-resident (186 KB per net),
-//     fetched two chunks ahead of the MFMAs that use them.
-//   * weight gradients contract over SAMPLES: the four wavefronts of a workgroup pool their tiles -- the split dZ and layer inputs go
-//     through an LDS transpose (three bf16 planes [neuron][128 samples]: written lane = sample, read 8 consecutive samples per lane as
-//     one ds_read_b128) -- and every 32 x 32 tile of every dW is OWNED by one wavefront, which accumulates it in registers over all
-//     samples the workgroup sees.  No atomics.  Bias gradients ride along as v_dot2 sums of the A fragments.  At the end a workgroup
-//     writes its tiles to a partial slab; mlp_grad_reduce_kernel sums the slabs in a fixed order into the flat gradient: deterministic.
+//     fetched two chunks ahead of the MFMAs that use them through a three-chunk register ring.
+//   * weight gradients contract over SAMPLES: the four wavefronts of a workgroup pool their tiles -- dZ and the layer inputs go through
+//     an fp32 LDS transpose ([neuron][128 samples + 4]: written lane = sample, read 8 consecutive samples per lane as two ds_read_b128)
+//     -- and every 32 x 32 tile of every dW is OWNED by one wavefront, which splits what it reads and accumulates the tile in registers
+//     over all samples the workgroup sees.  No atomics.  Bias gradients ride along as the running sum of the A operands.  At the end a
+//     workgroup writes its tiles to a partial slab; mlp_grad_reduce_kernel sums the slabs in a fixed order into the flat gradient: the
+//     step is deterministic.
+//   * the forward passes run as one chunk stream (each requests the next one's first weight chunks and leaves its last tile's tanh +
+//     split to the shadow of the next one's first MFMAs); the data-gradient passes request theirs before the publish barriers; the
+//     biases sit in LDS.  One wavefront per SIMD at ~480 registers: every latency that is not covered this way is paid in full.
 //   * the loss part is SB3's (amenv_train.hpp ppo_loss_grad, same expressions), evaluated on the accumulator tile of the head: the 7
 //     action means of a sample sit in registers 0..3 of the two lane halves.
 #pragma once
