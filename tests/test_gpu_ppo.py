@@ -450,8 +450,8 @@ def test_fused_rollout_feeds_the_update():
 
 @pytest.mark.parametrize("D,A,n", [(29, 7, 8192), (20, 4, 5000), (17, 4, 31), (29, 7, 65536)])
 def test_fused_mlp_step_matches_autograd(D, A, n):
-    """amenv_ppo_mlp_step (forward + SB3 loss + backward + all weight gradients of both MLPs in one kernel, fp32 on the matrix cores)
-    against autograd on the fp32 torch modules with the torch statement of the loss: every gradient entry within 2e-5 of the largest,
+    """amenv_ppo_mlp_step (forward + SB3 loss + backward + all weight gradients of both MLPs in one kernel; fp32 products, formed since round
+    3 from six bf16 MFMAs on exactly split operands -- the gate below is the fp32-MFMA version's, unchanged) against autograd on the fp32 torch modules with the torch statement of the loss: every gradient entry within 2e-5 of the largest,
     the four reported scalars equal; ragged batch sizes (n not a multiple of 32) included."""
     from rl_aerial_manipulator_amd.ppo import MinibatchStep
     torch.manual_seed(3)
@@ -490,6 +490,51 @@ def test_fused_mlp_step_matches_autograd(D, A, n):
         off += k
     assert torch.allclose(s0, s1, rtol=2e-4, atol=1e-6), (s0, s1)
     assert 0.02 < float(s1[3]) < 0.9                                       # clip fraction: the clipped branch was exercised
+
+
+@pytest.mark.parametrize("obs_scale,w_scale", [(0.7, 1.0), (0.02, 30.0), (6.0, 0.2)])
+def test_fused_mlp_step_is_as_accurate_as_fp32_autograd(obs_scale, w_scale):
+    """The split-bf16 products are fp32-grade: against the SAME loss differentiated in fp64, the fused kernel's gradient error is no larger
+    than a few times that of torch's own fp32 modules -- also with small inputs x large first-layer weights and the other way round (the three
+    bf16 parts carry 24 significant bits whatever the magnitude; a two-part split would be ~100 x worse and fail this)."""
+    from rl_aerial_manipulator_amd.ppo import MinibatchStep
+    D, A, n = 29, 7, 16384
+    torch.manual_seed(11)
+    pol = ActorCritic(D, A).cuda().flatten_()
+    with torch.no_grad():
+        pol.log_std.data.copy_(torch.linspace(-0.5, 0.1, A))
+        pol.mlp_extractor.policy_net[0].weight.mul_(w_scale)
+        pol.mlp_extractor.value_net[0].weight.mul_(w_scale)
+    opt = torch.optim.Adam([pol.flat_param.requires_grad_(True)], lr=1e-3)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    obs = torch.randn(n, D, device="cuda", generator=g) * obs_scale
+    with torch.no_grad():
+        mean = pol.action_net(pol.mlp_extractor.policy_net(obs))
+    actions = mean + torch.exp(pol.log_std.detach()) * torch.randn(n, A, device="cuda", generator=g)
+    with torch.no_grad():
+        _, logp, _ = pol.evaluate_actions(obs, actions)
+    old_logp = logp + 0.15 * torch.randn(n, device="cuda", generator=g)
+    adv = torch.randn(n, device="cuda", generator=g) * 3.0 + 0.5
+    ret = torch.randn(n, device="cuda", generator=g) * 2.0
+    grads = {}
+    for fused in (False, True):
+        step = MinibatchStep(pol, opt, clip_range=0.2, ent_coef=5e-4, vf_coef=0.5, use_graph=False, fused_loss=False, fused_mlp=fused)
+        assert step.fused_mlp == fused
+        pol.flat_grad.zero_()
+        step._forward_backward(obs, actions, old_logp, adv, ret)
+        grads[fused] = pol.flat_grad.double().clone()
+    pol64 = ActorCritic(D, A).cuda().double()
+    pol64.load_state_dict({k: v.double() for k, v in pol.state_dict().items() if k in pol64.state_dict()})
+    a64 = adv.double()
+    a64 = (a64 - a64.mean()) / (a64.std() + 1e-8)
+    values, logp64, ent = pol64.evaluate_actions(obs.double(), actions.double())
+    ratio = torch.exp(logp64 - old_logp.double())
+    loss = -torch.min(a64 * ratio, a64 * ratio.clamp(0.8, 1.2)).mean() - 5e-4 * ent.mean() + 0.5 * ((ret.double() - values) ** 2).mean()
+    g64 = torch.cat([x.reshape(-1) for x in torch.autograd.grad(loss, list(pol64.parameters()))])
+    scale = float(g64.abs().max())
+    e_torch, e_fused = float((grads[False] - g64).abs().max()) / scale, float((grads[True] - g64).abs().max()) / scale
+    print(f"obs x{obs_scale} W1 x{w_scale}: relative error vs fp64 autograd: torch fp32 {e_torch:.2e}, fused kernel {e_fused:.2e}")
+    assert e_fused < max(4.0 * e_torch, 2e-6), (e_fused, e_torch)
 
 
 def _mlp_problem(D, A, n, seed=1):
