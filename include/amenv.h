@@ -325,6 +325,13 @@ int amenv_gaussian_act(const float* mean, const float* log_std, const float* low
 int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, int64_t n, float* mean_out,
                          float* value_out, void* stream);
 
+/* amenv_policy_forward for large batches (the rollout buffer's values / log-probabilities, a 32768-env policy step): the same outputs
+ * from the training kernel's arithmetic -- fp32 products as six bf16 MFMAs on exactly split operands (see amenv_ppo_mlp_step) -- in two
+ * launches (weight packing, forward).  workspace: amenv_ppo_mlp_workspace_bytes() bytes, 16-byte aligned (the same area may serve
+ * amenv_ppo_mlp_step: both rewrite its weight part from flat_params on every call). */
+int amenv_policy_forward_mfma(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, int64_t n, float* mean_out,
+                              float* value_out, void* workspace, void* stream);
+
 /* Closed-loop rollout in ONE launch (SB3 collect_rollouts, v2/rl_train.py:38-56, for n_steps steps): per step
  *   obs_t -> actor / critic MLPs ([128, 64, 64] tanh; bf16 matrix cores, fp32 accumulate) -> a_t = mean + exp(log_std) z  (Philox keyed
  *   by (seed, global env id, draw0 + t) as amenv_gaussian_act) -> clip to the action box -> env step (as amenv_step, auto-reset included).

@@ -102,6 +102,7 @@ SYMBOLS = {
     "amenv_obsnorm_set": (C.c_int, [_P, _P, _P, C.c_double, _P]),
     "amenv_gae": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int64, C.c_float, C.c_float, _P]),
     "amenv_policy_forward": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P, _P]),
+    "amenv_policy_forward_mfma": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P, _P, _P]),
     "amenv_ppo_workspace_bytes": (C.c_size_t, []),
     "amenv_ppo_loss_grad": (C.c_int, [_P] * 7 + [C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "amenv_ppo_mlp_workspace_bytes": (C.c_size_t, []),

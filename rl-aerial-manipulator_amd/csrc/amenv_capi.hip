@@ -1117,6 +1117,23 @@ int amenv_policy_forward(const float* flat_params, int32_t obs_dim, int32_t act_
   return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
 }
 
+int amenv_policy_forward_mfma(const float* flat_params, int32_t obs_dim, int32_t act_dim, const float* obs, int64_t n, float* mean_out, float* value_out,
+                              void* workspace, void* stream) {
+  if (!flat_params || !obs || n <= 0 || (!mean_out && !value_out) || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u)) return AMENV_ERR_INVALID;
+  if (!((obs_dim == 20 && act_dim == 4) || (obs_dim == 29 && act_dim == 7) || (obs_dim == 17 && act_dim == 4))) return AMENV_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  uint16_t* WS = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + kMlpWsAdv);   // the split-weight area of amenv_ppo_mlp_step's workspace
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3((2 * kMlpPackThreadsPerNet + 255) / 256), dim3(256), 0, s, flat_params, (int)obs_dim, (int)act_dim, WS);
+  const int64_t ntiles = (n + 31) / 32;
+  const int nets = (mean_out ? 1 : 0) + (value_out ? 1 : 0);   // one wavefront per SIMD (~300 registers): 256 workgroups fill the chip
+  const dim3 grid((unsigned)std::min<int64_t>(256 / nets, (ntiles + 3) / 4), 2), block(256);
+  const u32x4* ws = reinterpret_cast<const u32x4*>(WS);
+  if (obs_dim == 20) hipLaunchKernelGGL((mlp_forward_kernel<20, 4>), grid, block, 0, s, flat_params, ws, obs, (int64_t)n, mean_out, value_out);
+  else if (obs_dim == 29) hipLaunchKernelGGL((mlp_forward_kernel<29, 7>), grid, block, 0, s, flat_params, ws, obs, (int64_t)n, mean_out, value_out);
+  else hipLaunchKernelGGL((mlp_forward_kernel<17, 4>), grid, block, 0, s, flat_params, ws, obs, (int64_t)n, mean_out, value_out);
+  return hipGetLastError() == hipSuccess ? AMENV_OK : AMENV_ERR_HIP;
+}
+
 size_t amenv_ppo_workspace_bytes(void) { return size_t(kPpoMaxBlocks) * (2 * sizeof(double) + kPpoPartial * sizeof(float)); }
 
 int amenv_ppo_loss_grad(const float* mean, const float* value, const float* log_std, const float* actions, const float* old_logp,

@@ -567,6 +567,57 @@ __global__ __launch_bounds__(256) void ppo_mlp_fused_kernel(const float* __restr
   if (threadIdx.x < 16) slab[kAccStats + threadIdx.x] = ((lstats[threadIdx.x] + lstats[16 + threadIdx.x]) + lstats[32 + threadIdx.x]) + lstats[48 + threadIdx.x];
 }
 
+// The forward passes alone: mean [n, A] = action_net(pi trunk(obs)), value [n] = value_net(vf trunk(obs)) for large batches (the rollout
+// buffer's log-probabilities / values, a vec-env's policy step), same arithmetic and weight stream as the training kernel.  grid =
+// (blocks, 2 nets), 256 threads; a wavefront takes 32 rows per iteration.  amenv_policy.hpp's VALU kernel stays for small batches.
+__global__ void mlp_pack_kernel(const float* __restrict__ Pm, int D, int A, uint16_t* __restrict__ WS) {
+  mlp_pack_element(Pm, D, A, WS, int(blockIdx.x * blockDim.x + threadIdx.x));
+}
+template <int D, int A>
+__global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restrict__ Pm, const u32x4* __restrict__ WS, const float* __restrict__ obs, int64_t n,
+                                                          float* __restrict__ mean, float* __restrict__ value) {
+  __shared__ __attribute__((aligned(16))) float lbias[kBiasFloats];
+  const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63, nn = lane & 31, h = lane >> 5;
+  const int net = blockIdx.y;
+  if ((net == 0 && !mean) || (net == 1 && !value)) return;   // whole workgroup: uniform
+  const MlpNet N = mlp_net(Pm, D, A, net);
+  for (int k = threadIdx.x; k < kBiasFloats; k += 256) {
+    const int k4 = k - (kH1 + kH2 + kH3);
+    lbias[k] = k < kH1 ? N.b1[k] : k < kH1 + kH2 ? N.b2[k - kH1] : k4 < 0 ? N.b3[k - kH1 - kH2] : k4 < N.n_out ? N.b4[k4] : 0.0f;
+  }
+  __syncthreads();
+  const u32x4* ws = WS + size_t(net) * kMlpFragsPerNet * 64;
+  uint32_t voff = uint32_t(lane) * 16u;
+  const int64_t ntiles = (n + 31) / 32;
+  for (int64_t tile = int64_t(blockIdx.x) * 4 + wave; tile < ntiles; tile += int64_t(gridDim.x) * 4) {   // (no barrier inside: a ragged tail is fine)
+    asm volatile("" : "+v"(voff));
+    const int64_t s = tile * 32 + nn;
+    const bool sv = s < n;
+    const int64_t sc = sv ? s : n - 1;
+    f32x16 X, H1[4], H2[2], H3[2], Y[1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const int k = mlp_rowmap(r) + 4 * h; const float x = obs[sc * D + (k < D ? k : D - 1)]; X[r] = k < D ? x : 0.0f; }
+    MlpRing ring;
+    Bf3 XS[1][2], H1S[4][2];
+    split_tile(X, XS[0]);
+    mlp_layer<0, kEpiTanh, true, 0, false, 1, true>(ring, ws, lbias, XS, H1, H1S, voff, h);
+    Bf3 H2S[2][2];
+    mlp_layer<1, kEpiTanh, true, 4 % 3, true, 2, true, true>(ring, ws, lbias, H1S, H2, H2S, voff, h, nullptr,
+                                                              [&](int e) { mlp_epi_pair<kEpiTanh, true>(H1[3], nullptr, H1S[3], e); });
+    Bf3 H3S[2][2];
+    mlp_layer<2, kEpiTanh, true, 12 % 3, true, 3, true, true>(ring, ws, lbias, H2S, H3, H3S, voff, h, nullptr,
+                                                               [&](int e) { mlp_epi_pair<kEpiTanh, true>(H2[1], nullptr, H2S[1], e); });
+    mlp_layer<3, kEpiNone, false, 16 % 3, true, -1, false, true>(ring, ws, lbias, H3S, Y, nullptr, voff, h, nullptr,
+                                                                  [&](int e) { mlp_epi_pair<kEpiTanh, true>(H3[1], nullptr, H3S[1], e); });
+    if (sv) {   // head rows 0..3 in lane half 0, 4..7 in half 1
+      if (net == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (r + 4 * h < A) mean[s * A + r + 4 * h] = Y[0][r];
+      } else if (h == 0) value[s] = Y[0][0];
+    }
+  }
+}
+
 // Fixed-order sum of the per-workgroup slabs into the flat gradient (SB3 parameter order) + d log_std + the four reported scalars.
 // 512 threads = 64 outputs x 8 slab groups: a wavefront reads 64 consecutive slots of one slab (coalesced), the (up to 16) loads of its
 // group in flight together; the group sums meet in LDS and are added in group order.

@@ -110,6 +110,7 @@ class ActorCritic(nn.Module):
 
     # ---- forward pieces -----------------------------------------------------------------------
     _FUSED_DIMS = {(20, 4), (29, 7), (17, 4)}
+    MFMA_FORWARD_ROWS = 8192   # batches from here on take amenv_policy_forward_mfma (below: the VALU kernel's shorter latency wins)
 
     def fused_ok(self, obs):
         """The one-launch HIP forward (`amenv_policy_forward`) applies: inference on the GPU, parameters in the flat buffer,
@@ -120,14 +121,20 @@ class ActorCritic(nn.Module):
 
     def forward_fused(self, obs, want_mean=True, want_value=True):
         """mean [n, A] and / or value [n] of a batch of observations in ONE kernel launch (weights as scalar operands of the FMAs,
-        activations through LDS; csrc/amenv_policy.hpp) instead of 14 library kernels."""
+        activations through LDS; csrc/amenv_policy.hpp) instead of 14 library kernels; large batches on the matrix cores (two launches)."""
         obs = obs.contiguous()
         n = obs.shape[0]
         mean = torch.empty(n, self.act_dim, dtype=torch.float32, device=obs.device) if want_mean else None
         value = torch.empty(n, dtype=torch.float32, device=obs.device) if want_value else None
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        rc = L.load().amenv_policy_forward(p(self.flat_param.detach()), self.obs_dim, self.act_dim, p(obs), n, p(mean), p(value),
-                                           C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        if n >= self.MFMA_FORWARD_ROWS:   # large batches: the training kernel's forward passes (matrix cores, csrc/amenv_mlp_train.hpp)
+            ws = self.__dict__.get("_fwd_ws")
+            if ws is None or ws.device != obs.device:
+                ws = self.__dict__["_fwd_ws"] = torch.empty(L.load().amenv_ppo_mlp_workspace_bytes() // 8 + 2, dtype=torch.float64, device=obs.device)
+            rc = L.load().amenv_policy_forward_mfma(p(self.flat_param.detach()), self.obs_dim, self.act_dim, p(obs), n, p(mean), p(value), p(ws), stream)
+        else:
+            rc = L.load().amenv_policy_forward(p(self.flat_param.detach()), self.obs_dim, self.act_dim, p(obs), n, p(mean), p(value), stream)
         if rc != 0:
             raise L.AmenvError(f"amenv_policy_forward failed ({rc})")
         return mean, value

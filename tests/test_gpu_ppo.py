@@ -293,9 +293,10 @@ def test_fused_ppo_loss_kernel_matches_autograd(A, normalize):
 
 
 @pytest.mark.parametrize("D,A", [(20, 4), (29, 7), (17, 4)])
-@pytest.mark.parametrize("n", [1, 64, 1000, 32768])
+@pytest.mark.parametrize("n", [1, 64, 1000, 10007, 32768])
 def test_fused_policy_forward_matches_torch_modules(D, A, n):
-    """amenv_policy_forward (one launch: scalar-operand weights, LDS activations) against the torch modules it replaces on the
+    """amenv_policy_forward (one launch: scalar-operand weights, LDS activations; n < 8192) and amenv_policy_forward_mfma (the training
+    kernel's forward passes on the matrix cores; larger n, ragged last tile included) against the torch modules they replace on the
     inference path, for the three (obs, action) shapes of the envs."""
     torch.manual_seed(D * 100 + A)
     pol = ActorCritic(D, A).to("cuda").flatten_()
