@@ -6,7 +6,8 @@
 // closed-loop rollout.  Here it is ONE launch:
 //   * grid = (tiles of 64 envs, 2 nets); a workgroup of NW waves evaluates one trunk for one tile, lane = env;
 //   * the weights are wave-uniform, so they travel through SCALAR loads and enter `v_fma_f32` as SGPR operands -- no weight ever
-//     touches a VGPR or LDS (fp32 MFMA issues at the VALU FMA rate on gfx950, so there is nothing to gain from it at fp32);
+//     touches a VGPR or LDS (fp32 MFMA issues at the VALU FMA rate on gfx950, so there is nothing to gain from it at fp32; from 8,192
+//     rows on ppo.py takes amenv_mlp_train.hpp's mlp_forward_kernel instead: fp32 products from bf16 MFMAs on split operands);
 //   * each wave computes a 1/NW slice of every layer's outputs for its 64 envs and hands the activations to the other waves through
 //     LDS ([neuron][lane], conflict-free), three barriers per evaluation.
 // Parameters are read from the policy's flat buffer in SB3's state-dict order (ppo.py ActorCritic.flatten_):
