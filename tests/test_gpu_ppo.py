@@ -449,7 +449,7 @@ def test_fused_rollout_feeds_the_update():
     env.close()
 
 
-@pytest.mark.parametrize("D,A,n", [(29, 7, 8192), (20, 4, 5000), (17, 4, 31), (29, 7, 65536)])
+@pytest.mark.parametrize("D,A,n", [(29, 7, 8192), (20, 4, 5000), (17, 4, 31), (29, 7, 65536), (20, 4, 20011)])   # 20011: two tile rounds, the second ragged
 def test_fused_mlp_step_matches_autograd(D, A, n):
     """amenv_ppo_mlp_step (forward + SB3 loss + backward + all weight gradients of both MLPs in one kernel; fp32 products, formed since round
     3 from six bf16 MFMAs on exactly split operands -- the gate below is the fp32-MFMA version's, unchanged) against autograd on the fp32 torch modules with the torch statement of the loss: every gradient entry within 2e-5 of the largest,
