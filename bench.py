@@ -444,6 +444,29 @@ def extras(args, amd, torch, env, ring, n, device):
     if args.vehicle != "quad":
         prot["reference_vehicle"] = {"vehicle": "quad (v2/simul_files/model/params.py: the vehicle the reference trains)", "envs": n, **closed_loop_pair("quad")}
     ex["survey_8d"] = {"steps": S, "warmup": GRAPH_CHUNK, "repeats": 5, "statistic": "median", **prot}
+    # row f3 (config 5's update): one PPO minibatch step of the reference's policy at 65,536 samples -- forward, SB3 loss, backward and all weight
+    # gradients of both MLPs in the fused HIP kernel (csrc/amenv_mlp_train.hpp: fp32 products from bf16 MFMAs on exactly split operands) + its
+    # prologue and gradient-reduce launches; synthetic samples of the benchmark vehicle's shapes
+    try:
+        from rl_aerial_manipulator_amd.ppo import MinibatchStep
+        nb = 65536
+        e5 = amd.GpuWaypointEnv(64, device=device.index, vehicle=args.vehicle, seed=0)
+        D5, A5 = e5.obs_dim, e5.act_dim
+        e5.close()
+        pol = amd.ActorCritic(D5, A5).to(device).flatten_()
+        opt = torch.optim.Adam([pol.flat_param.requires_grad_(True)], lr=1e-3)
+        gen = torch.Generator(device=device).manual_seed(5)
+        r = lambda *sh: torch.randn(*sh, device=device, generator=gen)  # noqa: E731
+        b_obs, b_act, b_olp, b_adv, b_ret = r(nb, D5), r(nb, A5), r(nb) * 0.1 - 5.0, r(nb), r(nb)
+        step = MinibatchStep(pol, opt, use_graph=False, fused_mlp=True)
+        for _ in range(3):
+            step._forward_backward(b_obs, b_act, b_olp, b_adv, b_ret)
+        ms = timed(lambda: [step._forward_backward(b_obs, b_act, b_olp, b_adv, b_ret) for _ in range(20)], 5)
+        ex["ppo_minibatch_step"] = {"samples": nb, "obs_dim": D5, "act_dim": A5, "us_per_forward_backward": ms * 1e3 / 20,
+                                    "samples_per_s": 20 * nb / (ms * 1e-3), "fused_kernel": bool(step.fused_mlp),
+                                    "what": "prologue (advantage sums, weight packing) + ppo_mlp_fused_kernel + fixed-order gradient reduce, back to back"}
+    except Exception as exc:   # an extra: never takes the headline line down
+        ex["ppo_minibatch_step"] = {"error": repr(exc)}
     return ex
 
 
