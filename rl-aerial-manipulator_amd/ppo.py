@@ -189,6 +189,9 @@ class ActorCritic(nn.Module):
             p.grad = grad[off:off + k].view_as(p)
             off += k
         self.flat_param, self.flat_grad = flat, grad
+        if flat.is_cuda and (self.obs_dim, self.act_dim) in self._FUSED_DIMS and self.net_arch == (128, 64, 64):
+            # workspace of the matrix-core forward (forward_fused, large batches): allocated here, never inside a graph capture
+            self.__dict__["_fwd_ws"] = torch.empty(L.load().amenv_ppo_mlp_workspace_bytes() // 8 + 2, dtype=torch.float64, device=flat.device)
         return self
 
     def num_parameters(self):
