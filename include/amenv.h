@@ -368,7 +368,7 @@ int amenv_ppo_loss_grad(const float* mean, const float* value, const float* log_
 /* One whole PPO minibatch step of the reference's policy ([128, 64, 64] tanh actor + critic, v2/rl_train.py:27-30,38-53) in ONE fused
  * kernel (+ a launch in front that packs the weights as MFMA operands and a fixed-order reduction behind): forward of both MLPs, SB3's
  * loss as amenv_ppo_loss_grad computes it, backward through both MLPs, all weight / bias gradients.  fp32 in and out on the matrix
- * cores: every operand is split exactly into three bf16 parts and a product is the sum of the six partial products above 2^-16
+ * cores: every operand is split exactly into three bf16 parts (each rounded to nearest) and a product is the sum of the six partial products above 2^-16
  * (v_mfma_f32_32x32x16_bf16, fp32 accumulation; what is dropped is below one fp32 rounding), so the result is as close to the same loss in
  * fp64 as autograd on the fp32 torch modules is (tests/test_gpu_ppo.py).  flat_params / flat_grad: the policy's parameters / their gradients in SB3 state-dict order (see
  * amenv_policy_forward); obs [n, obs_dim], actions [n, act_dim], old_logp / advantages / returns [n] f32; stats4 as amenv_ppo_loss_grad.

@@ -3,7 +3,7 @@
 // all weight / bias gradients.  PyTorch ran this as ~90 library launches per minibatch (~0.9 ms for 65,536 samples, ~15 TFLOP/s).
 //
 // Arithmetic: fp32 in, fp32 out, on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 parts (x = hi + mid + lo,
-// 8 significant bits each, by truncation) and a product a b is formed from the six partial products of weight >= 2^-16
+// 8 significant bits each, each rounded to nearest) and a product a b is formed from the six partial products of weight >= 2^-16
 // (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid) by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped ones are below
 // 2^-23 |a b| -- the size of one fp32 rounding.  Round 2 ran the same data flow on v_mfma_f32_32x32x2_f32: on gfx950 that instruction
 // issues at the vector FMA rate (157 TFLOP/s) and shares its issue slots with the wavefront's other VALU work (tools/micro/mfma_rate.hip);
@@ -76,21 +76,28 @@ __device__ __forceinline__ float tanh_acc(float x) {   // 1 - 2 / (exp(2x) + 1):
   return fma_(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
 }
 
-// x = hi + mid + lo exactly, each part 8 significant bits (bf16 by truncation; lo needs no masking: what is left has <= 8 bits)
-__device__ __forceinline__ void split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-  hi = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(hi);
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  lo = __float_as_uint(r1 - __uint_as_float(mid));
+// x = hi + mid + lo EXACTLY, each part a bf16 value (8 significant bits), by rounding to nearest: hi = bf16(x), mid = bf16(x - hi), lo = x - hi -
+// mid (x has 24 bits: what is left after two 8-bit parts fits the third).  |mid| <= 2^-8 |hi|, |lo| <= 2^-8 |mid|, so the three products a
+// six-product sum drops (mid lo, lo mid, lo lo) are below 2^-23 |a b|; truncation instead of rounding costs the same instructions and drops
+// up to 2^-21 (tests/test_ppo_cpu.py restates both).  A pair at a time: v_cvt_pk_bf16_f32 rounds and packs two values in one instruction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float v0, float v1) {   // bf16(v0) in the low half, bf16(v1) in the high half
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
 }
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t even, uint32_t odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }   // (odd & 0xffff0000) | (even >> 16)
+__device__ __forceinline__ void split_pair_packed(float v0, float v1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = cvt_pk_bf16(v0, v1);
+  const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  lo = cvt_pk_bf16(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xffff0000u));
+}
 
 // the three bf16 parts of the 8 values of one k-group, packed as MFMA operands: p[part][d] = elements 2 d (low half), 2 d + 1 (high half)
 struct Bf3 { u32x4 p[3]; };
 __device__ __forceinline__ void split_pair(float v0, float v1, Bf3& s, int d) {
-  uint32_t h0, m0, l0, h1, m1, l1;
-  split3(v0, h0, m0, l0); split3(v1, h1, m1, l1);
-  s.p[0][d] = pack_hi16(h0, h1); s.p[1][d] = pack_hi16(m0, m1); s.p[2][d] = pack_hi16(l0, l1);
+  uint32_t h, m, l;
+  split_pair_packed(v0, v1, h, m, l);
+  s.p[0][d] = h; s.p[1][d] = m; s.p[2][d] = l;
 }
 template <int NQ = 2>
 __device__ __forceinline__ void split_tile(const f32x16& v, Bf3* s) {   // s[q]: registers 8 q .. 8 q + 7
@@ -152,10 +159,10 @@ __device__ __forceinline__ void mlp_pack_element(const float* __restrict__ Pm, i
     default: v = N.W2[k * kH1 + out]; break;
   }
   uint32_t part[3];
-  split3(v, part[0], part[1], part[2]);
+  split_pair_packed(v, 0.0f, part[0], part[1], part[2]);   // (the low halves: this element's parts)
   uint16_t* dst = WS + (size_t(net) * kMlpFragsPerNet + 3 * unit) * 512 + lane * 8 + j;
 #pragma unroll
-  for (int p = 0; p < 3; p++) dst[p * 512] = uint16_t(part[p] >> 16);
+  for (int p = 0; p < 3; p++) dst[p * 512] = uint16_t(part[p]);
 }
 // Everything the fused kernel needs beforehand in ONE launch (each launch in this chain costs ~4.7 us whatever it does): workgroups
 // [0, adv_blocks) sum the minibatch's advantages (ppo_adv_partials), the rest write the split-weight streams.  256 threads.

@@ -278,3 +278,43 @@ def test_evaluate_policy_counts_episodes_like_sb3():
     rs = np.array([r for v in first.values() for r in v])
     assert len(rs) == 16 and abs(mean - rs.mean()) < 1e-6 * abs(rs.mean()) and abs(std - rs.std()) < 1e-3 * max(1.0, rs.std())
     assert 10000 < mean < 26000
+
+
+def test_three_way_bf16_split_is_exact_and_six_products_are_fp32_grade():
+    """The arithmetic of csrc/amenv_mlp_train.hpp restated in numpy (split_pair_packed / the product list of prod_a, prod_b): x = hi + mid + lo
+    holds EXACTLY with every part a bf16 value (8 significant bits, rounded to nearest even as v_cvt_pk_bf16_f32 does), whatever the magnitude
+    or sign, and the six partial products of weight >= 2^-16 reproduce a b to 2^-23 relative -- an fp32 rounding, which is why the autograd
+    gate did not move.  Truncated parts (same instruction count) would drop up to 2^-21; a two-part split 2^-15."""
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.standard_normal(20000), rng.standard_normal(20000) * 1e-6, rng.standard_normal(20000) * 1e6,
+                        np.float32([1.0, -1.0, 0.0, 3.0e38, 1.2e-30, 0.99999994, -2.0000002])]).astype(np.float32)
+
+    def bf16(v, rne=True):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        if rne:
+            u = u + 0x7FFF + ((u >> 16) & 1)
+        return (u & 0xFFFF0000).astype(np.uint32).view(np.float32)
+
+    def split3(v, rne=True):
+        hi = bf16(v, rne)
+        r1 = (v - hi).astype(np.float32)
+        mid = bf16(r1, rne)
+        lo = (r1 - mid).astype(np.float32)
+        return hi, mid, lo
+
+    def six(pa, pb):
+        return sum(pa[i].astype(np.float64) * pb[j].astype(np.float64) for i, j in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)))
+
+    a, b = x[:60000:3], x[1:60000:3]
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    err = {}
+    for rne in (True, False):
+        hi, mid, lo = split3(x, rne)
+        for part in (hi, mid, lo):
+            assert np.all((part.view(np.uint32) & np.uint32(0xFFFF)) == 0)          # representable in bf16: the low 16 bits are zero
+        assert np.array_equal((hi.astype(np.float64) + mid.astype(np.float64)) + lo.astype(np.float64), x.astype(np.float64))   # exact
+        err[rne] = (np.abs(six(split3(a, rne), split3(b, rne)) - exact) / np.maximum(np.abs(exact), 1e-300)).max()
+    assert err[True] < 2.0 ** -23 and 2.0 ** -23 < err[False] < 2.0 ** -21, err
+    pa, pb = split3(a), split3(b)
+    two_part = sum(pa[i].astype(np.float64) * pb[j].astype(np.float64) for i, j in ((0, 0), (0, 1), (1, 0)))                    # what a hi + mid split would give
+    assert (np.abs(two_part - exact) / np.maximum(np.abs(exact), 1e-300)).max() > 2.0 ** -17
