@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--resume", default=None, help="SB3 zip / policy.pth to start from (rl_train.py:33-35)")
     ap.add_argument("--save", default="waypoint_controller_gpu")         # rl_train.py:57
     ap.add_argument("--vehicle", default="quad")
+    ap.add_argument("--seed", type=int, default=0, help="env reset stream, initial weights and action noise (one run = one seed: PPO on this task is seed-sensitive)")
     ap.add_argument("--moment-scale", type=float, default=None, help="N m per unit moment action (amenv_vehicle.moment_scale; the reference quadrotor: 0.1)")
     ap.add_argument("--fused-rollout", action="store_true", help="collect every rollout as ONE launch (amenv_rollout_policy: the policy on bf16 matrix cores inside the env loop; "
                                                                  "log-probs / values of the buffer re-evaluated in fp32); quadrotor, hexacopter, hexacopter + arm")
@@ -45,10 +46,10 @@ def main():
     if a.moment_scale is not None:
         cfg = amd._lib.default_config(a.vehicle, a.envs)
         cfg.vehicle.moment_scale = a.moment_scale
-        cfg.seed, cfg.env_id_offset = 0, sh.env_id_offset
-    env = amd.GpuWaypointEnv(a.envs, device=local, vehicle=a.vehicle, seed=0, env_id_offset=sh.env_id_offset, config=cfg)
+        cfg.seed, cfg.env_id_offset = a.seed, sh.env_id_offset
+    env = amd.GpuWaypointEnv(a.envs, device=local, vehicle=a.vehicle, seed=a.seed, env_id_offset=sh.env_id_offset, config=cfg)
     model = amd.PPO(env, learning_rate=2e-4, n_steps=a.n_steps, batch_size=a.envs * a.n_steps // 128, n_epochs=12, gamma=0.995,
-                    gae_lambda=0.9, clip_range=0.2, ent_coef=1e-4 if a.resume else 5e-4, dist=dist, fused_rollout=a.fused_rollout)
+                    gae_lambda=0.9, clip_range=0.2, ent_coef=1e-4 if a.resume else 5e-4, dist=dist, fused_rollout=a.fused_rollout, seed=a.seed)
     if a.resume:
         model.load_policy(a.resume)
     elif a.warm_start_pid is not None:
