@@ -73,6 +73,9 @@ def main():
         print("saved", model.save(a.save))
         mean_reward, std_reward = amd.evaluate_policy(model, env, n_eval_episodes=max(10, a.envs))      # rl_train.py:60-61
         print(f"Mean reward: {mean_reward} +/- {std_reward}")
+        if curve and curve[-1].get("success_rate", 1.0) < 0.5 and a.warm_start_pid is None and not a.resume:
+            print("this run stayed on the hover plateau (about one seed in six does within 90 M steps, profiles/r03/ppo_seed_sweep_quad/): "
+                  "try another --seed, or --warm-start-pid 3 (actor cloned from the PID baseline), which leaves it from the first iterations")
         if a.log_json:
             import json
             first90 = next((c["timesteps"] for c in curve if c["success_rate"] > 0.9), None)
