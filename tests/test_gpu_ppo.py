@@ -341,6 +341,37 @@ def test_fused_policy_forward_reproduces_recorded_actions_and_is_capturable():
     assert torch.equal(out, out2)
 
 
+def test_matrix_core_forward_reproduces_the_recorded_reference_actions():
+    """amenv_policy_forward_mfma (batches >= 8192 rows) on the reference checkpoint: every recorded observation of the four golden policy
+    episodes, tiled past the switch-over, gives the action the reference recorded (to 6e-6; the small-batch kernel's bar is 3e-6) and the
+    small-batch kernel's means and values to the same tolerance."""
+    import glob
+    pol = fixture_policy("cuda")
+    if pol.flat_param is None:
+        pol.flatten_()
+    obs_l, act_l = [], []
+    for f in sorted(glob.glob(os.path.join(GOLD, "policy_ep*.npz"))):
+        g = np.load(f)
+        obs_l.append(np.concatenate([g["obs0"][None], g["obs"][:-1]])); act_l.append(g["actions"])
+    obs = torch.from_numpy(np.concatenate(obs_l)).cuda()
+    rec = torch.from_numpy(np.concatenate(act_l)).cuda()
+    n = obs.shape[0]
+    reps = -(-pol.MFMA_FORWARD_ROWS // n) + 1
+    big = obs.repeat(reps, 1)[: reps * n - 5].contiguous()                       # ragged last tile
+    assert big.shape[0] >= pol.MFMA_FORWARD_ROWS
+    with torch.no_grad():
+        small_mean, small_value = pol.forward_fused(obs)                       # VALU kernel
+        big_mean, big_value = pol.forward_fused(big)                           # matrix cores
+    lo, hi = pol.action_low, pol.action_high
+    a = torch.minimum(torch.maximum(big_mean[:n], lo), hi)
+    err = float((a - rec).abs().max())
+    print(f"matrix-core forward vs the {n} recorded actions: max |difference| {err:.2e}")
+    assert err < 6e-6                                                            # (the small-batch kernel: 3e-6; two fp32 summation orders of a trained, stiff controller)
+    assert float((big_mean[:n] - small_mean).abs().max()) < 6e-6 * max(1.0, float(small_mean.abs().max()))
+    assert float((big_value[:n] - small_value).abs().max()) < 6e-6 * max(1.0, float(small_value.abs().max()))
+    assert torch.equal(big_mean[n:2 * n], big_mean[:n])                          # tiles are independent of their position
+
+
 def test_training_script_runs(tmp_path):
     """examples/rl_train_gpu.py (the reference's rl_train.py on the GPU stack) end to end for two small iterations: trains, saves
     a checkpoint whose policy.pth has SB3's layout, evaluates."""
