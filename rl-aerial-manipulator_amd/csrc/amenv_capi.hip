@@ -1125,8 +1125,8 @@ int amenv_policy_forward_mfma(const float* flat_params, int32_t obs_dim, int32_t
   uint16_t* WS = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + kMlpWsAdv);   // the split-weight area of amenv_ppo_mlp_step's workspace
   hipLaunchKernelGGL(mlp_pack_kernel, dim3((2 * kMlpPackThreadsPerNet + 255) / 256), dim3(256), 0, s, flat_params, (int)obs_dim, (int)act_dim, WS);
   const int64_t ntiles = (n + 31) / 32;
-  const int nets = (mean_out ? 1 : 0) + (value_out ? 1 : 0);   // one wavefront per SIMD (~300 registers): 256 workgroups fill the chip
-  const dim3 grid((unsigned)std::min<int64_t>(256 / nets, (ntiles + 3) / 4), 2), block(256);
+  const int nets = (mean_out ? 1 : 0) + (value_out ? 1 : 0);   // two wavefronts per SIMD (242 registers): 512 workgroups fill the chip
+  const dim3 grid((unsigned)std::min<int64_t>(512 / nets, (ntiles + 3) / 4), 2), block(256);
   const u32x4* ws = reinterpret_cast<const u32x4*>(WS);
   if (obs_dim == 20) hipLaunchKernelGGL((mlp_forward_kernel<20, 4>), grid, block, 0, s, flat_params, ws, obs, (int64_t)n, mean_out, value_out);
   else if (obs_dim == 29) hipLaunchKernelGGL((mlp_forward_kernel<29, 7>), grid, block, 0, s, flat_params, ws, obs, (int64_t)n, mean_out, value_out);

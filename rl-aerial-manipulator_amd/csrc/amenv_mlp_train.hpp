@@ -581,7 +581,7 @@ __global__ void mlp_pack_kernel(const float* __restrict__ Pm, int D, int A, uint
   mlp_pack_element(Pm, D, A, WS, int(blockIdx.x * blockDim.x + threadIdx.x));
 }
 template <int D, int A>
-__global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restrict__ Pm, const u32x4* __restrict__ WS, const float* __restrict__ obs, int64_t n,
+__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(const float* __restrict__ Pm, const u32x4* __restrict__ WS, const float* __restrict__ obs, int64_t n,
                                                           float* __restrict__ mean, float* __restrict__ value) {
   __shared__ __attribute__((aligned(16))) float lbias[kBiasFloats];
   const int wave = int(threadIdx.x) >> 6, lane = int(threadIdx.x) & 63, nn = lane & 31, h = lane >> 5;
